@@ -1,0 +1,237 @@
+"""ctypes bindings of oracle/liboracle.so (CPU restatement of the reference path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the alphazero_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.azo_table_create.restype = C.c_void_p
+        L.azo_tower_create.restype = C.c_void_p
+        L.azo_mcts_create.restype = C.c_void_p
+        L.azo_tower_blob_size.restype = C.c_size_t
+        L.azo_mcts_eval_count.restype = C.c_long
+        L.azo_philox_u32.restype = C.c_uint32
+        L.azo_philox_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def env_reset(N):
+    cells = np.zeros(N * N, np.uint8)
+    return cells, 0
+
+
+def env_step(N, K, cells, to_move, action):
+    cells = cells.copy()
+    tm = C.c_int(to_move)
+    rew = np.zeros(2, np.float32)
+    done = lib().azo_env_step(N, K, _p(cells, C.c_uint8), C.byref(tm), int(action), _p(rew, C.c_float))
+    return cells, tm.value, rew, done
+
+
+def env_planes(N, cells, to_move):
+    planes = np.zeros(3 * N * N, np.uint8)
+    lib().azo_env_planes(N, _p(np.ascontiguousarray(cells), C.c_uint8), int(to_move), _p(planes, C.c_uint8))
+    return planes.reshape(3, N, N)
+
+
+def env_legal(N, cells):
+    acts = np.zeros(N * N, np.int32)
+    k = lib().azo_env_legal(N, _p(np.ascontiguousarray(cells), C.c_uint8), _p(acts, C.c_int32))
+    return acts[:k].copy()
+
+
+def eval_hash(N, planes):
+    pol = np.zeros(N * N, np.float32)
+    val = np.zeros(2, np.float32)
+    planes = np.ascontiguousarray(planes, np.uint8).reshape(-1)
+    lib().azo_eval_hash(None, N, _p(planes, C.c_uint8), _p(pol, C.c_float), _p(val, C.c_float))
+    return pol, val
+
+
+def philox(seed, stream, counter, lane=0):
+    return int(lib().azo_philox_u32(seed, stream, counter, lane))
+
+
+def dirichlet(state, size, alpha=0.05):
+    st = C.c_uint64(state)
+    out = np.zeros(size, np.float32)
+    lib().azo_dirichlet(C.byref(st), size, C.c_float(alpha), _p(out, C.c_float))
+    return out, st.value
+
+
+class Table:
+    def __init__(self, N, planes=None, policy=None, value=None):
+        self.N = N
+        self.h = C.c_void_p(lib().azo_table_create(N))
+        if planes is not None:
+            for i in range(len(planes)):
+                self.add(planes[i], policy[i], value[i])
+
+    def add(self, planes, policy, value):
+        planes = np.ascontiguousarray(planes, np.uint8).reshape(-1)
+        policy = np.ascontiguousarray(policy, np.float32).reshape(-1)
+        value = np.ascontiguousarray(value, np.float32).reshape(-1)
+        lib().azo_table_add(self.h, _p(planes, C.c_uint8), _p(policy, C.c_float), _p(value, C.c_float))
+
+    def misses(self):
+        return lib().azo_table_misses(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().azo_table_destroy(self.h)
+            self.h = None
+
+
+class Tower:
+    def __init__(self, N, c_in, Cs, blob, c_out=1):
+        self.N, self.c_in, self.c_out = N, c_in, c_out
+        Cs = np.asarray(Cs, np.int32)
+        blob = np.ascontiguousarray(blob, np.float32)
+        need = lib().azo_tower_blob_size(N, c_in, c_out, _p(Cs, C.c_int), len(Cs))
+        assert need == blob.size, (need, blob.size)
+        self.h = C.c_void_p(lib().azo_tower_create(N, c_in, c_out, _p(Cs, C.c_int), len(Cs), _p(blob, C.c_float), C.c_size_t(blob.size)))
+        assert self.h
+
+    @staticmethod
+    def blob_size(N, c_in, Cs, c_out=1):
+        Cs = np.asarray(Cs, np.int32)
+        return lib().azo_tower_blob_size(N, c_in, c_out, _p(Cs, C.c_int), len(Cs))
+
+    def forward(self, boards):
+        boards = np.ascontiguousarray(boards, np.uint8)
+        B = boards.shape[0]
+        pol = np.zeros((B, self.c_out * self.N * self.N), np.float32)
+        val = np.zeros((B, 2), np.float32)
+        lib().azo_tower_forward(self.h, _p(boards, C.c_uint8), B, _p(pol, C.c_float), _p(val, C.c_float))
+        return pol, val
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().azo_tower_destroy(self.h)
+            self.h = None
+
+
+class MCTS:
+    """One reference MCTS<Env> instance at nthreads=1 (mcts.hpp:18-581)."""
+
+    def __init__(self, N, K, vl=3.0, c_puct=3.0, evaluator="hash", user=None):
+        L = lib()
+        self.N, self.K = N, K
+        self._keep = user
+        if evaluator == "hash":
+            fn, up = C.cast(L.azo_eval_hash, C.c_void_p), None
+        elif evaluator == "table":
+            fn, up = C.cast(L.azo_eval_table, C.c_void_p), user.h
+        elif evaluator == "tower":
+            fn, up = C.cast(L.azo_eval_tower, C.c_void_p), user.h
+        else:  # python callable (planes[3,N,N]) -> (policy, value)
+            def tramp(_u, n, planes, pol, val):
+                pl = np.ctypeslib.as_array(planes, shape=(3 * n * n,)).reshape(3, n, n)
+                p, v = evaluator(pl)
+                np.ctypeslib.as_array(pol, shape=(n * n,))[:] = np.asarray(p, np.float32).reshape(-1)
+                np.ctypeslib.as_array(val, shape=(2,))[:] = np.asarray(v, np.float32)
+            self._cb = EVAL_FN(tramp)
+            fn, up = C.cast(self._cb, C.c_void_p), None
+        self.h = C.c_void_p(L.azo_mcts_create(N, K, C.c_float(vl), C.c_float(c_puct), fn, up))
+
+    def search(self, history, budget, noise=None):
+        hist = np.ascontiguousarray(history, np.int32)
+        out = np.zeros(self.N * self.N, np.float32)
+        nz = None if noise is None else _p(np.ascontiguousarray(noise, np.float32), C.c_float)
+        rc = lib().azo_mcts_search(self.h, _p(hist, C.c_int32), len(hist), int(budget), nz, _p(out, C.c_float))
+        if rc != 0:
+            raise ValueError("illegal history")
+        return out
+
+    def clear(self):
+        lib().azo_mcts_clear(self.h)
+
+    def seed(self, s):
+        lib().azo_mcts_seed(self.h, C.c_uint64(s))
+
+    def root_n(self):
+        return lib().azo_mcts_root_n(self.h)
+
+    def eval_count(self):
+        return lib().azo_mcts_eval_count(self.h)
+
+    def dump(self):
+        L = lib()
+        n = L.azo_mcts_dump(self.h, 0, None, None, None, None, None, None)
+        d = {k: np.zeros(n, np.int32) for k in ("parent", "action", "n", "kind")}
+        d["v"] = np.zeros(n, np.float32)
+        d["p"] = np.zeros(n, np.float32)
+        L.azo_mcts_dump(self.h, n, _p(d["parent"], C.c_int32), _p(d["action"], C.c_int32), _p(d["n"], C.c_int32),
+                        _p(d["v"], C.c_float), _p(d["p"], C.c_float), _p(d["kind"], C.c_int32))
+        return d
+
+    def selfplay_game(self, budget, seed, slot, noise, avg_len, game_count, sample_counter, max_moves=None):
+        N = self.N
+        A = N * N
+        max_moves = max_moves or A
+        cells = np.zeros((max_moves, A), np.uint8)
+        tomove = np.zeros(max_moves, np.uint8)
+        policy = np.zeros((max_moves, A), np.float32)
+        actions = np.zeros(max_moves, np.int32)
+
+        class Res(C.Structure):
+            _fields_ = [("n_moves", C.c_int), ("reward", C.c_float * 2)]
+        res = Res()
+        al = C.c_float(avg_len)
+        gc = C.c_int64(game_count)
+        sc = C.c_uint32(sample_counter)
+        nz = None if noise is None else _p(np.ascontiguousarray(noise, np.float32), C.c_float)
+        n = lib().azo_selfplay_game(self.h, int(budget), C.c_uint64(seed), C.c_uint32(slot), nz, C.byref(al), C.byref(gc),
+                                    C.byref(sc), max_moves, _p(cells, C.c_uint8), _p(tomove, C.c_uint8),
+                                    _p(policy, C.c_float), _p(actions, C.c_int32), C.byref(res))
+        assert n > 0
+        return dict(n_moves=n, cells=cells[:n], to_move=tomove[:n], policy=policy[:n], actions=actions[:n],
+                    reward=np.array([res.reward[0], res.reward[1]], np.float32), avg_len=al.value,
+                    game_count=gc.value, sample_counter=sc.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().azo_mcts_destroy(self.h)
+            self.h = None
+
+
+def replay_symmetries(N, state, policy):
+    state = np.ascontiguousarray(state, np.uint8)
+    Cn = state.shape[0]
+    policy = np.ascontiguousarray(policy, np.float32)
+    so = np.zeros((8, Cn, N, N), np.uint8)
+    po = np.zeros((8, N, N), np.float32)
+    lib().azo_replay_symmetries(N, Cn, _p(state, C.c_uint8), _p(policy, C.c_float), _p(so, C.c_uint8), _p(po, C.c_float))
+    return so, po
+
+
+def canonical_tree(d):
+    """Tuple form of a BFS dump for exact comparison."""
+    return [(int(a), int(b), int(c), float(e), float(f), int(g)) for a, b, c, e, f, g in
+            zip(d["parent"], d["action"], d["n"], d["v"], d["p"], d["kind"])]
