@@ -1,0 +1,125 @@
+"""Deterministic synthetic tower weights and boards.
+
+The weight blob is a flat fp32 vector in the reference network's module
+registration order (network.hpp:106-114): CBlock, PHead, VHead, RBlock_0..;
+inside a module conv.weight, conv.bias, then per BatchNorm weight, bias,
+running_mean, running_var; VHead adds fc1.{weight,bias}, fc2.{weight,bias};
+RBlock_i is conv1.{w,b}, conv2.{w,b}, bn1.{w,b,rm,rv}, bn2.{w,b,rm,rv}.
+
+Values come from a counter-based splitmix64 stream so the same blob can be
+regenerated anywhere from (shape, seed) without shipping megabytes of floats.
+"""
+import numpy as np
+
+NETCONFIG2 = [128] * 10          # netconfig.hpp:54-55 -> 9 ResBlocks (network.hpp:105)
+
+
+def _splitmix64(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n, offset=0):
+    """n doubles in [0,1) from counter offset..offset+n of stream `seed`."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(offset, offset + n, dtype=np.uint64) + (np.uint64(seed) << np.uint64(40))
+        r = _splitmix64(idx)
+    return (r >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def blob_layout(N, c_in, Cs, c_out=1):
+    """[(name, shape)] in blob order."""
+    num_res = len(Cs) - 1
+    Ch = Cs[num_res - 1]
+    L = []
+
+    def conv(n, ci, co, k):
+        L.append((n + ".weight", (co, ci, k, k)))
+        L.append((n + ".bias", (co,)))
+
+    def bn(n, c):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            L.append((n + "." + s, (c,)))
+
+    conv("CBlock.conv", c_in, Cs[0], 3)
+    bn("CBlock.bn", Cs[0])
+    conv("PHead.conv", Ch, c_out, 1)
+    conv("VHead.conv", Ch, 1, 1)
+    bn("VHead.bn", 1)
+    L.append(("VHead.fc1.weight", (64, N * N)))
+    L.append(("VHead.fc1.bias", (64,)))
+    L.append(("VHead.fc2.weight", (2, 64)))
+    L.append(("VHead.fc2.bias", (2,)))
+    for i in range(num_res):
+        r = "RBlock_%d" % i
+        conv(r + ".conv1", Cs[i], Cs[i + 1], 3)
+        conv(r + ".conv2", Cs[i + 1], Cs[i + 1], 3)
+        bn(r + ".bn1", Cs[i + 1])
+        bn(r + ".bn2", Cs[i + 1])
+    return L
+
+
+def blob_size(N, c_in, Cs, c_out=1):
+    return int(sum(int(np.prod(s)) for _, s in blob_layout(N, c_in, Cs, c_out)))
+
+
+def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1):
+    """Random-init weights: conv/linear U(-1/sqrt(fan_in), +), BN statistics
+    randomised so that folding is exercised; head gains sharpen the outputs."""
+    parts = []
+    off = 0
+    for name, shape in blob_layout(N, c_in, Cs, c_out):
+        n = int(np.prod(shape))
+        u = uniform01(seed, n, off)
+        off += n
+        if name.endswith("running_var"):
+            x = 0.5 + u
+        elif name.endswith("running_mean"):
+            x = (u - 0.5) * 0.4
+        elif ".bn" in name and name.endswith("weight"):
+            x = 0.8 + 0.4 * u
+        elif ".bn" in name and name.endswith("bias"):
+            x = (u - 0.5) * 0.4
+        else:
+            if name.endswith("weight"):
+                fan_in = int(np.prod(shape[1:]))
+            else:  # bias of the layer whose weight precedes it
+                fan_in = prev_fan_in
+            bound = 1.0 / np.sqrt(fan_in)
+            x = (2.0 * u - 1.0) * bound
+            prev_fan_in = fan_in
+        if name == "PHead.conv.weight":
+            x = x * phead_gain
+        if name == "VHead.fc2.weight":
+            x = x * fc2_gain
+        if name == "VHead.bn.bias":
+            x = np.full(n, 0.5)
+        parts.append(x.astype(np.float32))
+    return np.concatenate(parts)
+
+
+def unpack_blob(blob, N, c_in, Cs, c_out=1):
+    out = {}
+    off = 0
+    for name, shape in blob_layout(N, c_in, Cs, c_out):
+        n = int(np.prod(shape))
+        out[name] = blob[off:off + n].reshape(shape)
+        off += n
+    assert off == blob.size
+    return out
+
+
+def random_boards(B, N, seed=0, occupancy=0.3):
+    """u8 planes [B,3,N,N]: stones of player 0 / player 1 / side to move."""
+    A = N * N
+    u = uniform01(seed + 1000, B * A).reshape(B, A)
+    side = uniform01(seed + 2000, B) < 0.5
+    p0 = u < occupancy / 2
+    p1 = (u >= occupancy / 2) & (u < occupancy)
+    planes = np.zeros((B, 3, A), np.uint8)
+    planes[:, 0] = p0
+    planes[:, 1] = p1
+    planes[:, 2] = side[:, None]
+    return planes.reshape(B, 3, N, N)

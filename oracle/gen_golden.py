@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the compiled reference (oracle/_ref/az_ref).
+
+Run in the authoring container only (needs /root/reference to build az_ref):
+    make -C oracle ref && python oracle/gen_golden.py
+The fixtures hold inputs and expected outputs only (no reference source):
+  mcts_<name>.npz   search_probs runs of the unmodified mcts.hpp at nthreads=1:
+                    noise, moves, per-step output policy, root n, BFS tree dump
+                    and the (planes -> policy,value) table the evaluator answered
+  tower_<name>.npz  PVNetwork::forward outputs of the unmodified network.hpp for
+                    seeded synthetic weights (regenerated from the seed by
+                    alphazero_amd/synth.py) on seeded boards
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from alphazero_amd import synth  # noqa: E402
+
+REF = os.path.join(HERE, "_ref", "az_ref")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+MCTS_CASES = [
+    # name, N, K, budget, n_moves, noise_seed, weight_seed
+    ("ttt_b100", 3, 3, 100, 9, 7, 0),
+    ("gomoku7_b200", 7, 5, 200, 4, 11, 1),
+    ("gomoku9_b150", 9, 5, 150, 3, 13, 2),
+]
+
+TOWER_CASES = [
+    # name, N, Cs, B, weight seed, phead gain, fc2 gain
+    ("n5_c16x3", 5, [16, 16, 16], 8, 3, 1.0, 1.0),
+    ("n9_cfg2", 9, synth.NETCONFIG2, 4, 4, 1.0, 1.0),
+    ("n15_cfg2", 15, synth.NETCONFIG2, 4, 5, 1.0, 1.0),
+    ("n15_cfg2_sharp", 15, synth.NETCONFIG2, 4, 6, 20.0, 20.0),
+    ("n3_cfg2", 3, synth.NETCONFIG2, 4, 7, 5.0, 5.0),
+]
+
+
+def gen_mcts(name, N, K, budget, n_moves, noise_seed, wseed):
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call([REF, "mcts", str(N), str(K), str(budget), str(n_moves), str(noise_seed), d, str(wseed)],
+                              stdout=subprocess.DEVNULL)
+        z = {}
+        for f in os.listdir(d):
+            if f.endswith(".npy"):
+                z[f[:-4]] = np.load(os.path.join(d, f))
+    np.savez_compressed(os.path.join(OUT, "mcts_%s.npz" % name), **z)
+    print("mcts", name, "steps", int(z["meta"][3]), "table", len(z["table_value"]))
+
+
+def gen_tower(name, N, Cs, B, wseed, pg, fg):
+    blob = synth.make_blob(N, 3, Cs, wseed, pg, fg)
+    boards = synth.random_boards(B, N, seed=wseed)
+    with tempfile.TemporaryDirectory() as d:
+        blob.tofile(os.path.join(d, "blob.bin"))
+        boards.tofile(os.path.join(d, "boards.bin"))
+        subprocess.check_call([REF, "tower", str(N), "3", os.path.join(d, "blob.bin"), os.path.join(d, "boards.bin"),
+                               str(B), os.path.join(d, "out")] + [str(c) for c in Cs])
+        pol = np.load(os.path.join(d, "out_policy.npy"))
+        val = np.load(os.path.join(d, "out_value.npy"))
+    np.savez_compressed(os.path.join(OUT, "tower_%s.npz" % name), N=N, Cs=np.array(Cs), B=B, wseed=wseed,
+                        phead_gain=pg, fc2_gain=fg, boards=boards, policy=pol, value=val)
+    print("tower", name, "pmax", pol.max(), "v", val.min(), val.max())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for c in TOWER_CASES:
+        gen_tower(*c)
+    for c in MCTS_CASES:
+        gen_mcts(*c)

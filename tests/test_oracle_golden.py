@@ -1,0 +1,48 @@
+"""The CPU oracle (oracle/az_oracle.cpp) against fixtures produced by the
+compiled, unmodified reference headers (oracle/gen_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import azo
+from alphazero_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MCTS_FIX = sorted(glob.glob(os.path.join(GOLDEN, "mcts_*.npz")))
+TOWER_FIX = sorted(glob.glob(os.path.join(GOLDEN, "tower_*.npz")))
+
+
+@pytest.mark.parametrize("path", MCTS_FIX, ids=[os.path.basename(p) for p in MCTS_FIX])
+def test_mcts_restatement_matches_reference_bit_exact(path):
+    z = np.load(path)
+    N, K, budget, steps, _done = [int(x) for x in z["meta"]]
+    tab = azo.Table(N, z["table_planes"], z["table_policy"], z["table_value"])
+    m = azo.MCTS(N, K, 3.0, 3.0, "table", tab)
+    hist = []
+    for s in range(steps):
+        pol = m.search(hist, budget, z["noise"])
+        assert np.array_equal(pol, z["policies"][s])          # bit-exact f32
+        assert m.root_n() == int(z["root_n"][s])
+        t = m.dump()
+        for k in ("parent", "action", "n", "kind", "v", "p"):
+            assert np.array_equal(t[k], z["step%d_%s" % (s, k)]), (s, k)
+        hist.append(int(z["moves"][s]))
+    assert tab.misses() == 0
+
+
+@pytest.mark.parametrize("path", TOWER_FIX, ids=[os.path.basename(p) for p in TOWER_FIX])
+def test_tower_restatement_matches_reference(path):
+    z = np.load(path)
+    N, Cs = int(z["N"]), [int(c) for c in z["Cs"]]
+    if N >= 15:
+        B = 1     # the scalar restatement needs ~1 s per 15x15 board
+    else:
+        B = int(z["B"])
+    blob = synth.make_blob(N, 3, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]))
+    t = azo.Tower(N, 3, Cs, blob)
+    pol, val = t.forward(z["boards"][:B])
+    # fp32 vs fp32 with a different summation order: tolerance 2e-5 abs
+    assert np.abs(pol - z["policy"][:B]).max() < 2e-5
+    assert np.abs(val - z["value"][:B]).max() < 2e-5
