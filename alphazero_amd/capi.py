@@ -1,0 +1,268 @@
+"""ctypes binding of libazhip.so (C ABI: include/az_hip.h).
+
+There is no CPU fallback: importing works anywhere (so the symbol table can be
+checked without a GPU) but every compute call needs an MI355X and raises
+AzError otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libazhip.so")
+
+AZ_EVAL_TOWER, AZ_EVAL_HASH, AZ_EVAL_EXTERNAL = 0, 1, 2
+AZ_NOISE_EXPLICIT, AZ_NOISE_DEVICE = 0, 1
+AZ_PREC_BF16, AZ_PREC_BF16X3 = 0, 1
+AZ_MAX_LAYERS = 64
+
+EXPORTS = [
+    "az_last_error", "az_ctx_create", "az_ctx_destroy", "az_sync", "az_stream", "az_weights_size",
+    "az_load_weights", "az_load_weights_dev", "az_env_reset", "az_env_step", "az_env_boards",
+    "az_env_legal_mask", "az_env_set", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
+    "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
+    "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
+    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read",
+]
+
+
+class AzError(RuntimeError):
+    pass
+
+
+class AzConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("N", C.c_int), ("K", C.c_int), ("G", C.c_int), ("n_Cs", C.c_int),
+        ("Cs", C.c_int * AZ_MAX_LAYERS), ("vl", C.c_float), ("c_puct", C.c_float), ("node_cap", C.c_int),
+        ("max_budget", C.c_int), ("eval_mode", C.c_int), ("noise_mode", C.c_int), ("precision", C.c_int),
+        ("seed", C.c_uint64), ("game_slot_base", C.c_int),
+    ]
+
+
+class AzStats(C.Structure):
+    _fields_ = [
+        ("sims", C.c_int64), ("evals", C.c_int64), ("rounds", C.c_int64), ("moves", C.c_int64),
+        ("games", C.c_int64), ("replay_rows", C.c_int64), ("replay_dropped", C.c_int64),
+        ("max_nodes", C.c_int32), ("max_edges", C.c_int32), ("error_games", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libazhip.so; fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AzError("libazhip.so not built (run `make -C alphazero_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.az_last_error.restype = C.c_char_p
+        L.az_weights_size.restype = C.c_size_t
+        L.az_stream.restype = C.c_void_p
+        L.az_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.az_load_weights_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.az_tower_forward_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise AzError("libazhip error %d: %s" % (rc, load().az_last_error().decode()))
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """G lockstep games on one GPU: the reference's MCTS<Env> + Evaluator<Env>
+    + PVNetwork (mcts.hpp, evaluator.hpp, network.hpp) behind one handle."""
+
+    def __init__(self, N, K, G, Cs=None, vl=3.0, c_puct=3.0, max_budget=800, node_cap=0,
+                 eval_mode=AZ_EVAL_TOWER, noise_mode=AZ_NOISE_EXPLICIT, precision=AZ_PREC_BF16,
+                 seed=0, device=0, game_slot_base=0):
+        L = load()
+        cfg = AzConfig()
+        cfg.device, cfg.N, cfg.K, cfg.G = device, N, K, G
+        Cs = list(Cs) if Cs is not None else []
+        cfg.n_Cs = len(Cs)
+        for i, c in enumerate(Cs):
+            cfg.Cs[i] = c
+        cfg.vl, cfg.c_puct = vl, c_puct
+        cfg.node_cap, cfg.max_budget = node_cap, max_budget
+        cfg.eval_mode, cfg.noise_mode, cfg.precision = eval_mode, noise_mode, precision
+        cfg.seed, cfg.game_slot_base = seed, game_slot_base
+        self.N, self.K, self.G, self.A = N, K, G, N * N
+        self.Cs = Cs
+        self.h = C.c_void_p()
+        _chk(L.az_ctx_create(C.byref(self.h), C.byref(cfg)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().az_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # -- weights (util.h load_network) -------------------------------------
+    def weights_size(self):
+        return load().az_weights_size(self.h)
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, np.float32)
+        _chk(load().az_load_weights(self.h, _ptr(blob), blob.size))
+
+    def load_weights_dev(self, dev_ptr, n_floats):
+        _chk(load().az_load_weights_dev(self.h, C.c_void_p(dev_ptr), n_floats))
+
+    # -- PVNetwork::forward ------------------------------------------------
+    def tower_forward(self, boards):
+        boards = np.ascontiguousarray(boards, np.uint8)
+        B = boards.shape[0]
+        pol = np.empty((B, self.A), np.float32)
+        val = np.empty((B, 2), np.float32)
+        _chk(load().az_tower_forward(self.h, _ptr(boards), B, _ptr(pol), _ptr(val)))
+        return pol, val
+
+    def tower_forward_dev(self, boards_ptr, B, policy_ptr, value_ptr):
+        _chk(load().az_tower_forward_dev(self.h, C.c_void_p(boards_ptr), B, C.c_void_p(policy_ptr), C.c_void_p(value_ptr)))
+
+    # -- Env ---------------------------------------------------------------
+    def env_reset(self):
+        _chk(load().az_env_reset(self.h))
+
+    def env_step(self, actions):
+        actions = np.ascontiguousarray(actions, np.int32)
+        reward = np.empty((self.G, 2), np.float32)
+        done = np.empty(self.G, np.uint8)
+        _chk(load().az_env_step(self.h, _ptr(actions), _ptr(reward), _ptr(done)))
+        return reward, done
+
+    def env_boards(self):
+        pl = np.empty((self.G, 3, self.N, self.N), np.uint8)
+        _chk(load().az_env_boards(self.h, _ptr(pl)))
+        return pl
+
+    def env_legal_mask(self):
+        m = np.empty((self.G, self.N, self.N), np.uint8)
+        _chk(load().az_env_legal_mask(self.h, _ptr(m)))
+        return m
+
+    def env_set(self, cells, to_move):
+        cells = np.ascontiguousarray(cells, np.uint8)
+        to_move = np.ascontiguousarray(to_move, np.uint8)
+        _chk(load().az_env_set(self.h, _ptr(cells), _ptr(to_move)))
+
+    # -- MCTS --------------------------------------------------------------
+    def set_noise(self, noise):
+        noise = np.ascontiguousarray(noise, np.float32)
+        assert noise.size == self.G * self.A
+        _chk(load().az_set_noise(self.h, _ptr(noise)))
+
+    def search(self, budget):
+        out = np.empty((self.G, self.A), np.float32)
+        _chk(load().az_search(self.h, int(budget), _ptr(out)))
+        return out
+
+    def search_begin(self, budget):
+        _chk(load().az_search_begin(self.h, int(budget)))
+
+    def search_select(self):
+        planes = np.empty((self.G, 3, self.N, self.N), np.uint8)
+        pending = np.empty(self.G, np.int32)
+        run = C.c_int()
+        _chk(load().az_search_select(self.h, _ptr(planes), _ptr(pending), C.byref(run)))
+        return planes, pending, run.value
+
+    def search_apply(self, policy, value):
+        policy = np.ascontiguousarray(policy, np.float32)
+        value = np.ascontiguousarray(value, np.float32)
+        _chk(load().az_search_apply(self.h, _ptr(policy), _ptr(value)))
+
+    def search_result(self):
+        out = np.empty((self.G, self.A), np.float32)
+        rn = np.empty(self.G, np.int32)
+        _chk(load().az_search_result(self.h, _ptr(out), _ptr(rn)))
+        return out, rn
+
+    def tree_clear(self):
+        _chk(load().az_tree_clear(self.h))
+
+    def tree_dump(self, game):
+        L = load()
+        nn, ne = C.c_int32(), C.c_int32()
+        _chk(L.az_tree_dump(self.h, game, 0, 0, C.byref(nn), C.byref(ne), None, None, None, None, None, None, None))
+        nn, ne = nn.value, ne.value
+        d = dict(node_first=np.zeros(nn, np.int32), node_count=np.zeros(nn, np.int32), p=np.zeros(ne, np.float32),
+                 n=np.zeros(ne, np.int32), v=np.zeros(ne, np.float32), child=np.zeros(ne, np.int32),
+                 action=np.zeros(ne, np.int32))
+        a, b = C.c_int32(), C.c_int32()
+        if nn:
+            _chk(L.az_tree_dump(self.h, game, nn, ne, C.byref(a), C.byref(b), _ptr(d["node_first"]), _ptr(d["node_count"]),
+                                _ptr(d["p"]), _ptr(d["n"]), _ptr(d["v"]), _ptr(d["child"]), _ptr(d["action"])))
+        return d
+
+    def tree_canonical(self, game):
+        """BFS dump in the oracle's format: (parent, action, n, v, p, kind)."""
+        d = self.tree_dump(game)
+        out = []
+        if len(d["node_first"]) == 0:
+            return out
+        q = [0]
+        qi = 0
+        while qi < len(q):
+            node = q[qi]
+            fe, ne = int(d["node_first"][node]), int(d["node_count"][node])
+            for e in range(fe, fe + ne):
+                ch = int(d["child"][e])
+                kind = 1 if ch >= 0 else {-1: 0, -2: 2, -3: 3, -4: 4}[ch]
+                out.append((qi, int(d["action"][e]), int(d["n"][e]), float(d["v"][e]), float(d["p"][e]), kind))
+                if ch >= 0:
+                    q.append(ch)
+            qi += 1
+        return out
+
+    # -- generate.cpp on the device ------------------------------------------
+    def selfplay_begin(self, budget):
+        _chk(load().az_selfplay_begin(self.h, int(budget)))
+
+    def selfplay_run(self, rounds):
+        _chk(load().az_selfplay_run(self.h, int(rounds)))
+
+    def replay_drain(self, cap=1 << 16):
+        cells = np.empty((cap, self.A), np.uint8)
+        tm = np.empty(cap, np.uint8)
+        pol = np.empty((cap, self.A), np.float32)
+        rew = np.empty((cap, 2), np.float32)
+        n = _chk(load().az_replay_drain(self.h, cap, _ptr(cells), _ptr(tm), _ptr(pol), _ptr(rew)))
+        return cells[:n], tm[:n], pol[:n], rew[:n]
+
+    def stats(self):
+        s = AzStats()
+        _chk(load().az_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in AzStats._fields_}
+
+    def sync(self):
+        _chk(load().az_sync(self.h))
+
+    def profile_enable(self, every):
+        _chk(load().az_profile_enable(self.h, int(every)))
+
+    def profile_read(self):
+        ca, ta = C.c_double(), C.c_double()
+        cn, tn = C.c_int64(), C.c_int64()
+        _chk(load().az_profile_read(self.h, C.byref(ca), C.byref(cn), C.byref(ta), C.byref(tn)))
+        return dict(conv_avg_us=ca.value, conv_launches=cn.value, tree_avg_us=ta.value, tree_launches=tn.value)
+
+
+def replay_symmetries(N, cells, to_move, policy):
+    cells = np.ascontiguousarray(cells, np.uint8)
+    policy = np.ascontiguousarray(policy, np.float32)
+    so = np.empty((8, 3, N, N), np.uint8)
+    po = np.empty((8, N, N), np.float32)
+    _chk(load().az_replay_symmetries(N, _ptr(cells), int(to_move), _ptr(policy), _ptr(so), _ptr(po)))
+    return so, po

@@ -1,0 +1,646 @@
+// api.hip -- the C ABI of libazhip.so (include/az_hip.h): context, weights,
+// batched env, tower forward, lockstep search and device-side self-play.
+// Host code only; kernels live in tree.hip and tower.hip.
+#include "../../include/az_hip.h"
+#include "az_dev.h"
+#include "az_tower.h"
+#include "az_tree.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail(AZ_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define AZCHK(call) do { int r_ = (call); if (r_ != AZ_OK) return r_; } while (0)
+
+extern "C" const char* az_last_error(void) { return g_err.c_str(); }
+
+struct az_ctx {
+    az_config cfg;
+    hipStream_t stream = nullptr;
+    AzTreeDev d;
+    std::vector<void*> allocs;
+    int A = 0, P = 0, W = 0, Gd = 0, C = 0, C_pad = 0, num_res = 0;
+    int Bmax = 0;
+    // tower
+    bool have_weights = false;
+    unsigned short *actX = nullptr, *actH = nullptr;      // [rows][C_pad] bf16
+    size_t act_rows = 0;
+    float *stem_w = nullptr, *stem_b = nullptr;           // [C_pad][27], [C_pad]
+    unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
+    float* conv_b = nullptr;                              // [2*num_res][C_pad]
+    float* head_p = nullptr;
+    size_t conv_layer_elems = 0;
+    uint8_t* tower_in = nullptr;                          // staging for az_tower_forward [Bmax][3][A]
+    float *tower_pol = nullptr, *tower_val = nullptr;
+    // misc device scratch
+    int* d_actions = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; int* d_illegal = nullptr;
+    int mode = AZ_MODE_SEARCH;
+    bool search_active = false;
+    int64_t rounds = 0;
+    // HIP-event sampling of the conv / tree kernels on the context's stream
+    int prof_every = 0;
+    int64_t prof_calls = 0;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_used = 0;
+    std::vector<std::pair<size_t, int>> prof_spans;       // (first event index, kind 0 conv / 1 tree)
+};
+
+static bool prof_begin(az_ctx* c, int kind, bool sampled) {
+    if (!sampled || c->prof_used + 2 > c->prof_pool.size()) return false;
+    c->prof_spans.push_back({c->prof_used, kind});
+    hipEventRecord(c->prof_pool[c->prof_used], c->stream);
+    return true;
+}
+static void prof_end(az_ctx* c, bool on) {
+    if (!on) return;
+    hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream);
+    c->prof_used += 2;
+}
+
+template <class T>
+static int dalloc(az_ctx* c, T** p, size_t n, bool zero = true) {
+    void* q = nullptr;
+    const size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(AZ_E_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) { e = hipMemset(q, 0, bytes); if (e != hipSuccess) return fail(AZ_E_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
+    c->allocs.push_back(q);
+    *p = (T*)q;
+    return AZ_OK;
+}
+
+static size_t weights_size(int N, int c_in, const int* Cs, int n_Cs) {
+    auto conv = [](size_t ci, size_t co, size_t k) { return co * ci * k * k + co; };
+    const int num_res = n_Cs - 1, Ch = Cs[num_res - 1];
+    size_t s = conv(c_in, Cs[0], 3) + 4 * (size_t)Cs[0] + conv(Ch, 1, 1) + conv(Ch, 1, 1) + 4 +
+               (size_t)64 * N * N + 64 + 128 + 2;
+    for (int i = 0; i < num_res; ++i) s += conv(Cs[i], Cs[i + 1], 3) + conv(Cs[i + 1], Cs[i + 1], 3) + 8 * (size_t)Cs[i + 1];
+    return s;
+}
+
+extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
+    if (!out || !cfg) return fail(AZ_E_ARG, "null argument");
+    if (cfg->N < 3 || cfg->N * cfg->N > 512 - 64) return fail(AZ_E_ARG, "board side %d unsupported (3..21)", cfg->N);
+    if (cfg->K < 2 || cfg->K > 8 || cfg->K > cfg->N) return fail(AZ_E_ARG, "win length %d unsupported (2..8, <= N)", cfg->K);
+    if (cfg->G < 1) return fail(AZ_E_ARG, "G must be >= 1");
+    if (cfg->eval_mode == AZ_EVAL_TOWER) {
+        if (cfg->n_Cs < 2 || cfg->n_Cs > AZ_MAX_LAYERS) return fail(AZ_E_ARG, "n_Cs %d out of range", cfg->n_Cs);
+        for (int i = 1; i < cfg->n_Cs; ++i)
+            if (cfg->Cs[i] != cfg->Cs[0])
+                return fail(AZ_E_ARG, "ResBlock widths must be uniform (x + input, network.hpp:36)");
+        if (cfg->precision != AZ_PREC_BF16) return fail(AZ_E_ARG, "precision %d not available in this build", cfg->precision);
+    }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(AZ_E_HIP, "no HIP device: libazhip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(AZ_E_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+    az_ctx* c = new az_ctx;
+    c->cfg = *cfg;
+    const int N = cfg->N, A = N * N, G = cfg->G;
+    c->A = A; c->W = N + 1; c->P = c->W * c->W; c->Gd = N + 2;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    AzTreeDev& d = c->d;
+    memset(&d, 0, sizeof d);
+    d.G = G; d.N = N; d.A = A; d.K = cfg->K;
+    const int mb = cfg->max_budget > 0 ? cfg->max_budget : 800;
+    d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : 4 * mb + 64;
+    if (d.node_cap > 36000) return fail(AZ_E_ARG, "node_cap %d exceeds the LDS queue limit", d.node_cap);
+    d.edge_cap = (int)std::min<long long>((long long)d.node_cap * A, 2000000000ll);
+    d.path_cap = A + 1;
+    d.vl = cfg->vl; d.c_puct_i = (int)cfg->c_puct;
+    d.noise_mode = cfg->noise_mode; d.seed = cfg->seed; d.slot_base = cfg->game_slot_base;
+    d.budget = mb;
+#define DA(field, n) AZCHK(dalloc(c, &d.field, (size_t)(n)))
+    DA(cells, (size_t)G * A); DA(to_move, G); DA(hist_len, G); DA(hist, (size_t)G * A);
+    DA(game_over, G); DA(final_reward, 2 * (size_t)G);
+    DA(arena, G);
+    for (int a = 0; a < 2; ++a) {
+        AZCHK(dalloc(c, &d.nodes[a], (size_t)G * d.node_cap, false));
+        AZCHK(dalloc(c, &d.edges[a], (size_t)G * d.edge_cap, false));
+        AZCHK(dalloc(c, &d.eact[a], (size_t)G * d.edge_cap, false));
+    }
+    DA(n_nodes, G); DA(n_edges, G); DA(root_n, G); DA(root_hist_len, G); DA(root_hist, (size_t)G * A);
+    DA(status, G); DA(sims_done, G); DA(sims_target, G); DA(pending, G); DA(path_len, G);
+    DA(path, (size_t)G * d.path_cap); DA(pend_result, 2 * (size_t)G); DA(err, G);
+    DA(leaf_planes, (size_t)G * 3 * A); DA(policy, (size_t)G * A); DA(value, 2 * (size_t)G);
+    DA(noise, (size_t)G * A); DA(out_policy, (size_t)G * A);
+    DA(move_idx, G); DA(avg_len, G); DA(game_count, G); DA(sample_ctr, G); DA(noise_ctr, G);
+    DA(row_cells, (size_t)G * A * A); DA(row_tomove, (size_t)G * A); DA(row_policy, (size_t)G * A * A);
+    d.ring_cap = std::max(4 * G * A / 2, 4096);
+    DA(ring_cells, (size_t)d.ring_cap * A); DA(ring_tomove, d.ring_cap);
+    DA(ring_policy, (size_t)d.ring_cap * A); DA(ring_reward, 2 * (size_t)d.ring_cap);
+    DA(counters, 16);
+#undef DA
+    HIPCHK(hipMemset(d.root_hist_len, 0xFF, sizeof(int) * G));      // -1: no tree
+    {   // uniform noise default so an unset buffer is still a distribution
+        std::vector<float> nz((size_t)G * A, 1.0f / (float)A);
+        HIPCHK(hipMemcpy(d.noise, nz.data(), nz.size() * 4, hipMemcpyHostToDevice));
+    }
+    AZCHK(dalloc(c, &c->d_actions, G)); AZCHK(dalloc(c, &c->d_reward, 2 * (size_t)G));
+    AZCHK(dalloc(c, &c->d_done, G)); AZCHK(dalloc(c, &c->d_illegal, 4));
+    if (az_tree_configure(&d) != 0) return fail(AZ_E_HIP, "tree kernel LDS configuration failed (node_cap %d)", d.node_cap);
+
+    c->Bmax = G;
+    if (cfg->eval_mode == AZ_EVAL_TOWER) {
+        c->C = cfg->Cs[0];
+        c->C_pad = (c->C + 127) / 128 * 128;
+        c->num_res = cfg->n_Cs - 1;
+        const size_t M_pad = ((size_t)c->Bmax * c->P + 255) / 256 * 256;
+        c->act_rows = M_pad + 2 * (size_t)c->Gd;
+        AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
+        AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
+        AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27)); AZCHK(dalloc(c, &c->stem_b, c->C_pad));
+        c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
+        AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
+        AZCHK(dalloc(c, &c->conv_b, (size_t)2 * c->num_res * c->C_pad));
+        AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
+        AZCHK(dalloc(c, &c->tower_in, (size_t)c->Bmax * 3 * A));
+        AZCHK(dalloc(c, &c->tower_pol, (size_t)c->Bmax * A)); AZCHK(dalloc(c, &c->tower_val, 2 * (size_t)c->Bmax));
+        if (az_tower_configure() != 0) return fail(AZ_E_HIP, "tower kernel LDS configuration failed");
+    }
+    HIPCHK(hipDeviceSynchronize());
+    *out = c;
+    return AZ_OK;
+}
+
+extern "C" int az_ctx_destroy(az_ctx* c) {
+    if (!c) return AZ_OK;
+    hipSetDevice(c->cfg.device);
+    hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) hipFree(p);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return AZ_OK;
+}
+
+extern "C" int az_sync(az_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return AZ_OK; }
+extern "C" void* az_stream(az_ctx* c) { return (void*)c->stream; }
+
+// ----------------------------------------------------------------- weights
+extern "C" size_t az_weights_size(const az_ctx* c) {
+    return weights_size(c->cfg.N, 3, c->cfg.Cs, c->cfg.n_Cs);
+}
+
+static inline unsigned short host_f2bf(float x) {
+    unsigned u; memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// BatchNorm (eval, eps 1e-5: network.hpp:13,29-30,71) folded into the preceding
+// convolution in double; 3x3 kernels re-laid as [nb][sc][tap][kc][n][k] chunks.
+extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    if (n_floats != az_weights_size(c)) return fail(AZ_E_ARG, "blob has %zu floats, expected %zu", n_floats, az_weights_size(c));
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int N = c->cfg.N, A = N * N, C = c->C, Cp = c->C_pad, nres = c->num_res;
+    const float* p = blob;
+    struct Conv { const float *w, *b; };
+    struct Bn { const float *g, *b, *rm, *rv; };
+    auto conv = [&](size_t ci, size_t co, size_t k) { Conv r{p, p + co * ci * k * k}; p += co * ci * k * k + co; return r; };
+    auto bn = [&](size_t ch) { Bn r{p, p + ch, p + 2 * ch, p + 3 * ch}; p += 4 * ch; return r; };
+    const Conv stem = conv(3, C, 3); const Bn stem_bn = bn(C);
+    const Conv pc = conv(C, 1, 1);
+    const Conv vc = conv(C, 1, 1); const Bn vbn = bn(1);
+    const float* fc1w = p; p += (size_t)64 * A; const float* fc1b = p; p += 64;
+    const float* fc2w = p; p += 128; const float* fc2b = p; p += 2;
+    std::vector<Conv> c1(nres), c2(nres); std::vector<Bn> b1(nres), b2(nres);
+    for (int i = 0; i < nres; ++i) { c1[i] = conv(C, C, 3); c2[i] = conv(C, C, 3); b1[i] = bn(C); b2[i] = bn(C); }
+
+    auto scale = [](const Bn& b, int ch) { return (double)b.g[ch] / std::sqrt((double)b.rv[ch] + 1e-5); };
+    // stem: fp32 [Cp][27]
+    std::vector<float> sw((size_t)Cp * 27, 0.f), sb(Cp, 0.f);
+    for (int co = 0; co < C; ++co) {
+        const double s = scale(stem_bn, co);
+        for (int k = 0; k < 27; ++k) sw[(size_t)co * 27 + k] = (float)(stem.w[(size_t)co * 27 + k] * s);
+        sb[co] = (float)(((double)stem.b[co] - stem_bn.rm[co]) * s + stem_bn.b[co]);
+    }
+    HIPCHK(hipMemcpy(c->stem_w, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->stem_b, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
+    // residual convolutions
+    const int nblk = Cp / 128;
+    std::vector<unsigned short> pk(c->conv_layer_elems * 2 * nres, 0);
+    std::vector<float> cb((size_t)2 * nres * Cp, 0.f);
+    for (int L = 0; L < 2 * nres; ++L) {
+        const Conv& cv = (L & 1) ? c2[L / 2] : c1[L / 2];
+        const Bn& bb = (L & 1) ? b2[L / 2] : b1[L / 2];
+        unsigned short* dst = pk.data() + (size_t)L * c->conv_layer_elems;
+        for (int co = 0; co < C; ++co) {
+            const double s = scale(bb, co);
+            cb[(size_t)L * Cp + co] = (float)(((double)cv.b[co] - bb.rm[co]) * s + bb.b[co]);
+            const int nb = co / 128, n = co % 128;
+            for (int ci = 0; ci < C; ++ci) {
+                const int sc = ci / 128, kc = (ci % 128) / 64, k = ci % 64;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const size_t chunk = (((size_t)nb * nblk + sc) * 9 + tap) * 2 + kc;
+                    dst[chunk * (128 * 64) + (size_t)n * 64 + k] =
+                        host_f2bf((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
+                }
+            }
+        }
+    }
+    HIPCHK(hipMemcpy(c->conv_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->conv_b, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
+    // heads
+    std::vector<float> hp((size_t)2 * Cp + 2 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
+    const double vs = scale(vbn, 0);
+    for (int ch = 0; ch < C; ++ch) { hp[ch] = pc.w[ch]; hp[Cp + ch] = (float)(vc.w[ch] * vs); }
+    hp[2 * Cp] = pc.b[0];
+    hp[2 * Cp + 1] = (float)(((double)vc.b[0] - vbn.rm[0]) * vs + vbn.b[0]);
+    float* q = hp.data() + 2 * Cp + 2;
+    memcpy(q, fc1w, sizeof(float) * 64 * A); q += 64 * A;
+    memcpy(q, fc1b, sizeof(float) * 64); q += 64;
+    memcpy(q, fc2w, sizeof(float) * 128); q += 128;
+    memcpy(q, fc2b, sizeof(float) * 2);
+    HIPCHK(hipMemcpy(c->head_p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    c->have_weights = true;
+    return AZ_OK;
+}
+
+extern "C" int az_load_weights_dev(az_ctx* c, const float* blob_dev, size_t n_floats) {
+    std::vector<float> h(n_floats);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpy(h.data(), blob_dev, n_floats * 4, hipMemcpyDeviceToHost));
+    return az_load_weights(c, h.data(), n_floats);
+}
+
+// ------------------------------------------------------------------- tower
+static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev) {
+    if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
+    if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
+    const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
+    const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
+    az_launch_stem(c->stream, planes_dev, c->actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
+    for (int i = 0; i < c->num_res; ++i) {
+        const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
+        const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
+        bool on = prof_begin(c, 0, sampled);
+        az_launch_conv3x3(c->stream, c->actX, c->actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
+        prof_end(c, on);
+        on = prof_begin(c, 0, sampled);
+        az_launch_conv3x3(c->stream, c->actH, c->actX, c->actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        prof_end(c, on);
+    }
+    az_launch_heads(c->stream, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+    HIPCHK(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    return tower_run(c, boards_dev, B, policy_dev, value_dev);
+}
+
+extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* policy, float* value) {
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t A = c->A;
+    HIPCHK(hipMemcpyAsync(c->tower_in, boards, (size_t)B * 3 * A, hipMemcpyHostToDevice, c->stream));
+    AZCHK(tower_run(c, c->tower_in, B, c->tower_pol, c->tower_val));
+    HIPCHK(hipMemcpyAsync(policy, c->tower_pol, (size_t)B * A * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(value, c->tower_val, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------------- env
+extern "C" int az_env_reset(az_ctx* c) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    az_launch_env_reset(c->stream, &c->d);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_env_step(az_ctx* c, const int32_t* actions, float* reward, uint8_t* done) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G;
+    HIPCHK(hipMemcpyAsync(c->d_actions, actions, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_illegal, 0, 16, c->stream));
+    az_launch_env_step(c->stream, &c->d, c->d_actions, c->d_reward, c->d_done, c->d_illegal);
+    int illegal = 0;
+    HIPCHK(hipMemcpyAsync(reward, c->d_reward, sizeof(float) * 2 * G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(done, c->d_done, G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&illegal, c->d_illegal, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (illegal) return fail(AZ_E_ARG, "%d illegal action(s): occupied cell, out of range, or finished game", illegal);
+    return AZ_OK;
+}
+
+extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    az_launch_env_export(c->stream, &c->d, c->d.leaf_planes, nullptr);
+    HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)c->cfg.G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_env_legal_mask(az_ctx* c, uint8_t* mask) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    // borrow the first G*A bytes of the row staging area
+    az_launch_env_export(c->stream, &c->d, nullptr, c->d.row_tomove);
+    HIPCHK(hipMemcpyAsync(mask, c->d.row_tomove, (size_t)c->cfg.G * c->A, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_env_set(az_ctx* c, const uint8_t* cells, const uint8_t* to_move) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G, A = c->A;
+    // a position set directly has no move history: it is its own history origin
+    std::vector<int> zeros(G, 0);
+    std::vector<uint8_t> z8(G, 0);
+    HIPCHK(hipMemcpy(c->d.cells, cells, (size_t)G * A, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.to_move, to_move, G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.game_over, z8.data(), G, hipMemcpyHostToDevice));
+    // history length = number of stones so that "board full" detection stays right
+    std::vector<int> hl(G);
+    for (int g = 0; g < G; ++g) { int s = 0; for (int i = 0; i < A; ++i) s += cells[(size_t)g * A + i] != 0; hl[g] = s; }
+    HIPCHK(hipMemcpy(c->d.hist_len, hl.data(), sizeof(int) * G, hipMemcpyHostToDevice));
+    std::vector<uint16_t> hist((size_t)G * A, 0xFFFF);
+    HIPCHK(hipMemcpy(c->d.hist, hist.data(), hist.size() * 2, hipMemcpyHostToDevice));
+    return az_tree_clear(c);
+}
+
+extern "C" int az_set_noise(az_ctx* c, const float* noise) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpy(c->d.noise, noise, (size_t)c->cfg.G * c->A * 4, hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
+extern "C" int az_tree_clear(az_ctx* c) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G;
+    HIPCHK(hipMemsetAsync(c->d.root_hist_len, 0xFF, sizeof(int) * G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.n_nodes, 0, sizeof(int) * G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.n_edges, 0, sizeof(int) * G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.root_n, 0, sizeof(int) * G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.status, 0, sizeof(int) * G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.pending, 0, sizeof(int) * G, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->search_active = false;
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------ search
+static int run_evaluator(az_ctx* c) {
+    if (c->cfg.eval_mode == AZ_EVAL_TOWER)
+        return tower_run(c, c->d.leaf_planes, c->cfg.G, c->d.policy, c->d.value);
+    if (c->cfg.eval_mode == AZ_EVAL_HASH) {
+        az_launch_eval_hash(c->stream, c->d.leaf_planes, c->d.policy, c->d.value, c->cfg.G, c->A);
+        return AZ_OK;
+    }
+    return fail(AZ_E_STATE, "external evaluator: drive the search with az_search_select/apply");
+}
+
+static int check_errors(az_ctx* c) {
+    std::vector<int> err(c->cfg.G);
+    HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * c->cfg.G, hipMemcpyDeviceToHost));
+    for (int g = 0; g < c->cfg.G; ++g)
+        if (err[g] == 1) return fail(AZ_E_CAPACITY, "game %d: tree arena full (node_cap %d); raise az_config.node_cap", g, c->d.node_cap);
+        else if (err[g]) return fail(AZ_E_STATE, "game %d: no selectable child (mcts.hpp:374-375)", g);
+    return AZ_OK;
+}
+
+extern "C" int az_search_begin(az_ctx* c, int budget) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (budget > c->d.budget && c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
+        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget %d", budget, c->d.budget);
+    c->mode = AZ_MODE_SEARCH;
+    az_launch_begin(c->stream, &c->d, budget);
+    HIPCHK(hipGetLastError());
+    c->search_active = true;
+    return AZ_OK;
+}
+
+extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
+    if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "external evaluator: use az_search_select/apply");
+    AZCHK(az_search_begin(c, budget));
+    const int b = budget > 1 ? budget : 1;
+    // every game needs b simulations plus, for a fresh root, one root evaluation;
+    // round r applies evaluation r-1 and issues evaluation r
+    for (int r = 0; r < b + 2; ++r) {
+        az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH);
+        if (r < b + 1) AZCHK(run_evaluator(c));
+        c->rounds++;
+    }
+    HIPCHK(hipGetLastError());
+    return az_search_result(c, out_policy, nullptr);
+}
+
+extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, int* n_running) {
+    if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G;
+    az_launch_round(c->stream, &c->d, 2, AZ_MODE_SEARCH);
+    std::vector<int> st(G);
+    HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pending, c->d.pending, sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(st.data(), c->d.status, sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int run = 0;
+    for (int g = 0; g < G; ++g) { run += st[g] == AZ_ST_RUN; if (st[g] != AZ_ST_RUN) pending[g] = 0; }
+    *n_running = run;
+    c->rounds++;
+    return check_errors(c);
+}
+
+extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* value) {
+    if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G;
+    HIPCHK(hipMemcpyAsync(c->d.policy, policy, (size_t)G * c->A * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d.value, value, (size_t)G * 2 * 4, hipMemcpyHostToDevice, c->stream));
+    az_launch_round(c->stream, &c->d, 1, AZ_MODE_SEARCH);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_search_result(az_ctx* c, float* out_policy, int32_t* root_n) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    AZCHK(check_errors(c));
+    std::vector<int> st(G);
+    HIPCHK(hipMemcpy(st.data(), c->d.status, sizeof(int) * G, hipMemcpyDeviceToHost));
+    for (int g = 0; g < G; ++g)
+        if (st[g] == AZ_ST_RUN) return fail(AZ_E_STATE, "game %d has not finished its search", g);
+    if (out_policy) HIPCHK(hipMemcpy(out_policy, c->d.out_policy, (size_t)G * c->A * 4, hipMemcpyDeviceToHost));
+    if (root_n) HIPCHK(hipMemcpy(root_n, c->d.root_n, sizeof(int) * G, hipMemcpyDeviceToHost));
+    c->search_active = false;
+    return AZ_OK;
+}
+
+extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int32_t* n_nodes, int32_t* n_edges,
+                            int32_t* node_first, int32_t* node_count, float* edge_p, int32_t* edge_n,
+                            float* edge_v, int32_t* edge_child, int32_t* edge_action) {
+    if (game < 0 || game >= c->cfg.G) return fail(AZ_E_ARG, "game %d out of range", game);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int nn = 0, ne = 0, ar = 0, rhl = -1;
+    HIPCHK(hipMemcpy(&nn, c->d.n_nodes + game, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ne, c->d.n_edges + game, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ar, c->d.arena + game, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&rhl, c->d.root_hist_len + game, 4, hipMemcpyDeviceToHost));
+    if (rhl < 0) { nn = 0; ne = 0; }
+    *n_nodes = nn; *n_edges = ne;
+    if (node_cap == 0 && edge_cap == 0) return AZ_OK;
+    if (node_cap < nn || edge_cap < ne) return fail(AZ_E_ARG, "dump buffers too small (%d nodes, %d edges)", nn, ne);
+    std::vector<int2> nd(nn);
+    std::vector<AzEdge> ed(ne);
+    std::vector<uint16_t> ea(ne);
+    HIPCHK(hipMemcpy(nd.data(), c->d.nodes[ar] + (size_t)game * c->d.node_cap, sizeof(int2) * nn, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ed.data(), c->d.edges[ar] + (size_t)game * c->d.edge_cap, sizeof(AzEdge) * ne, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ea.data(), c->d.eact[ar] + (size_t)game * c->d.edge_cap, 2 * (size_t)ne, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nn; ++i) { node_first[i] = nd[i].x; node_count[i] = nd[i].y; }
+    for (int i = 0; i < ne; ++i) {
+        edge_p[i] = ed[i].p; edge_n[i] = ed[i].n; edge_v[i] = ed[i].v; edge_child[i] = ed[i].child; edge_action[i] = ea[i];
+    }
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------- self-play
+extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
+    if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "self-play needs a device evaluator");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (4 * budget + 64 > c->d.node_cap && c->cfg.node_cap == 0)
+        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget %d", budget, c->d.budget);
+    c->d.budget = budget > 1 ? budget : 1;
+    c->mode = AZ_MODE_SELFPLAY;
+    HIPCHK(hipMemsetAsync(c->d.counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d.err, 0, sizeof(int) * c->cfg.G, c->stream));
+    az_launch_selfplay_begin(c->stream, &c->d);
+    // issue the first evaluation so that every later round is evaluate -> tree
+    az_launch_round(c->stream, &c->d, 2, AZ_MODE_SELFPLAY);
+    HIPCHK(hipGetLastError());
+    c->search_active = false;
+    return AZ_OK;
+}
+
+extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
+    if (c->mode != AZ_MODE_SELFPLAY) return fail(AZ_E_STATE, "az_selfplay_begin has not been called");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    for (int r = 0; r < rounds; ++r) {
+        AZCHK(run_evaluator(c));
+        const bool on = prof_begin(c, 1, c->prof_every > 0 && (c->rounds % c->prof_every) == 0);
+        az_launch_round(c->stream, &c->d, 3, AZ_MODE_SELFPLAY);
+        prof_end(c, on);
+        c->rounds++;
+    }
+    HIPCHK(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, c->d.counters + 4, 8, hipMemcpyDeviceToHost));
+    const size_t A = c->A;
+    const int n = (int)std::min<unsigned long long>(cnt, (unsigned long long)cap);
+    if (n > 0) {
+        HIPCHK(hipMemcpy(cells, c->d.ring_cells, (size_t)n * A, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(to_move, c->d.ring_tomove, n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(policy, c->d.ring_policy, (size_t)n * A * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(reward, c->d.ring_reward, (size_t)n * 2 * 4, hipMemcpyDeviceToHost));
+    }
+    if ((unsigned long long)n < cnt) {        // keep the tail: shift it to the front
+        const size_t rest = (size_t)(cnt - n);
+        HIPCHK(hipMemcpy(c->d.ring_cells, c->d.ring_cells + (size_t)n * A, rest * A, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(c->d.ring_tomove, c->d.ring_tomove + n, rest, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(c->d.ring_policy, c->d.ring_policy + (size_t)n * A, rest * A * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(c->d.ring_reward, c->d.ring_reward + (size_t)n * 2, rest * 8, hipMemcpyDeviceToDevice));
+    }
+    cnt -= n;
+    HIPCHK(hipMemcpy(c->d.counters + 4, &cnt, 8, hipMemcpyHostToDevice));
+    return n;
+}
+
+extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long k[16];
+    HIPCHK(hipMemcpy(k, c->d.counters, sizeof k, hipMemcpyDeviceToHost));
+    std::vector<int> err(c->cfg.G);
+    HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * c->cfg.G, hipMemcpyDeviceToHost));
+    memset(s, 0, sizeof *s);
+    s->sims = (int64_t)k[0]; s->evals = (int64_t)k[1]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
+    s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
+    s->max_nodes = (int32_t)k[6]; s->max_edges = (int32_t)k[7];
+    s->rounds = c->rounds;
+    for (int e : err) s->error_games += e != 0;
+    return AZ_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+extern "C" int az_profile_enable(az_ctx* c, int every) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->prof_every = every;
+    c->prof_calls = 0;
+    c->prof_used = 0;
+    c->prof_spans.clear();
+    if (every > 0 && c->prof_pool.empty()) {
+        c->prof_pool.resize(8192);
+        for (auto& e : c->prof_pool) HIPCHK(hipEventCreate(&e));
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_profile_read(az_ctx* c, double* conv_avg_us, int64_t* conv_launches,
+                               double* tree_avg_us, int64_t* tree_launches) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double sum[2] = {0, 0};
+    int64_t cnt[2] = {0, 0};
+    for (auto& sp : c->prof_spans) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_pool[sp.first], c->prof_pool[sp.first + 1]));
+        sum[sp.second] += ms * 1000.0;
+        cnt[sp.second]++;
+    }
+    *conv_avg_us = cnt[0] ? sum[0] / cnt[0] : 0.0; *conv_launches = cnt[0];
+    *tree_avg_us = cnt[1] ? sum[1] / cnt[1] : 0.0; *tree_launches = cnt[1];
+    return AZ_OK;
+}
+
+// replay.hpp:80-112 (host helper): rot90(r,{1,2}) then .flip(1), r = 0..3.
+extern "C" int az_replay_symmetries(int N, const uint8_t* cells, int to_move, const float* policy,
+                                    uint8_t* states_out, float* policies_out) {
+    if (N < 1 || !cells || !policy || !states_out || !policies_out) return fail(AZ_E_ARG, "null argument");
+    const int A = N * N;
+    int v = 0;
+    for (int r = 0; r < 4; ++r)
+        for (int f = 0; f < 2; ++f, ++v)
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j) {
+                    const int ii = f ? N - 1 - i : i;
+                    int sy, sx;
+                    if (r == 0) { sy = ii; sx = j; }
+                    else if (r == 1) { sy = j; sx = N - 1 - ii; }
+                    else if (r == 2) { sy = N - 1 - ii; sx = N - 1 - j; }
+                    else { sy = N - 1 - j; sx = ii; }
+                    const uint8_t cv = cells[sy * N + sx];
+                    uint8_t* so = states_out + (size_t)v * 3 * A;
+                    so[i * N + j] = cv == 1;
+                    so[A + i * N + j] = cv == 2;
+                    so[2 * A + i * N + j] = (uint8_t)to_move;
+                    policies_out[(size_t)v * A + i * N + j] = policy[sy * N + sx];
+                }
+    return AZ_OK;
+}

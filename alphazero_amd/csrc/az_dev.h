@@ -1,0 +1,111 @@
+// Shared device-side definitions of libazhip (tree / env state in HBM).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One child stub = one reference Node before add() (node.hpp:21-22,63-67):
+// prior p, visits n, total value v; q is v/n (recomputed, identical bits).
+// child: >=0 id of the expanded node, -1 stub, -2/-3/-4 terminal leaf whose
+// stored reward is {+1,-1} / {-1,+1} / {0,0} (Node::terminal_add, node.hpp:36-42).
+struct __attribute__((aligned(16))) AzEdge {
+    float p;
+    int   n;
+    float v;
+    int   child;
+};
+
+enum { AZ_PEND_NONE = 0, AZ_PEND_ROOT = 1, AZ_PEND_LEAF = 2, AZ_PEND_TERMINAL = 3 };
+enum { AZ_ST_IDLE = 0, AZ_ST_RUN = 1 };
+enum { AZ_MODE_SEARCH = 0, AZ_MODE_SELFPLAY = 1 };
+
+// All per-game state, structure-of-arrays over the G games of one GPU.
+struct AzTreeDev {
+    int G, N, A, K;
+    int node_cap, edge_cap;     // per game, per arena
+    int path_cap;               // A + 1
+    float vl;
+    int c_puct_i;               // Node::ucb takes int (node.hpp:47)
+    int noise_mode;
+    unsigned long long seed;
+    int slot_base;
+    int budget;                 // selfplay: iter_budget of every search
+
+    // real game (= root position)
+    uint8_t*  cells;            // [G][A]
+    uint8_t*  to_move;          // [G]
+    int*      hist_len;         // [G]
+    uint16_t* hist;             // [G][A]
+    uint8_t*  game_over;        // [G]
+    float*    final_reward;     // [G][2]
+
+    // tree arenas (ping-pong for re-root compaction)
+    int*      arena;            // [G] 0/1
+    int2*     nodes[2];         // [G][node_cap] {first_edge, num_edges}
+    AzEdge*   edges[2];         // [G][edge_cap]
+    uint16_t* eact[2];          // [G][edge_cap] action (cell index) of each edge
+    int*      n_nodes;          // [G]
+    int*      n_edges;          // [G]
+    int*      root_n;           // [G]
+    int*      root_hist_len;    // [G] -1 = no tree
+    uint16_t* root_hist;        // [G][A]
+
+    // search state
+    int*      status;           // [G]
+    int*      sims_done;        // [G]
+    int*      sims_target;      // [G]
+    int*      pending;          // [G]
+    int*      path_len;         // [G]
+    int*      path;             // [G][path_cap] edge indices root->leaf
+    float*    pend_result;      // [G][2] reward of a terminal leaf
+    int*      err;              // [G] sticky error flag (arena overflow)
+
+    // evaluator I/O
+    uint8_t*  leaf_planes;      // [G][3][A]
+    float*    policy;           // [G][A]
+    float*    value;            // [G][2]
+    float*    noise;            // [G][A]
+    float*    out_policy;       // [G][A]
+
+    // self-play
+    int*      move_idx;         // [G] moves played in the current game
+    float*    avg_len;          // [G] running mean game length (generate.cpp:69)
+    long long* game_count;      // [G]
+    unsigned* sample_ctr;       // [G]
+    unsigned* noise_ctr;        // [G]
+    uint8_t*  row_cells;        // [G][A][A]
+    uint8_t*  row_tomove;       // [G][A]
+    float*    row_policy;       // [G][A][A]
+    // replay ring
+    int       ring_cap;
+    uint8_t*  ring_cells;       // [ring_cap][A]
+    uint8_t*  ring_tomove;      // [ring_cap]
+    float*    ring_policy;      // [ring_cap][A]
+    float*    ring_reward;      // [ring_cap][2]
+    // counters: [0] sims [1] evals [2] moves [3] games [4] ring rows [5] dropped
+    // [6] max nodes [7] max edges
+    unsigned long long* counters;
+};
+
+__host__ __device__ inline unsigned long long az_splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Philox4x32-10, ctr = {counter, stream, 0, 0}, key = {seed lo, seed hi}.
+__host__ __device__ inline void az_philox4(unsigned long long seed, unsigned stream, unsigned counter, unsigned out[4]) {
+    unsigned c0 = counter, c1 = stream, c2 = 0u, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = 0xD2511F53ull * c0;
+        unsigned long long p1 = 0xCD9E8D57ull * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        unsigned n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}

@@ -1,0 +1,15 @@
+// Host-side launchers of the tower kernels (tower.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+extern "C" {
+int  az_tower_configure(void);
+void az_launch_stem(hipStream_t s, const uint8_t* planes, unsigned short* out, const float* w,
+                    const float* bias, int B, int N, int C_pad, int Gd);
+void az_launch_conv3x3(hipStream_t s, const unsigned short* in, unsigned short* out,
+                       const unsigned short* resid, const unsigned short* wpk, const float* bias,
+                       int C_pad, int M, int N, int Gd, int relu);
+void az_launch_heads(hipStream_t s, const unsigned short* x, const float* hp, float* policy,
+                     float* value, int B, int N, int C_pad, int Gd);
+}

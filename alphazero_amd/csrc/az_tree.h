@@ -1,0 +1,15 @@
+// Host-side launchers of the environment / tree kernels (tree.hip).
+#pragma once
+#include "az_dev.h"
+
+extern "C" {
+int  az_tree_configure(const AzTreeDev* d);
+void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode);
+void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget);
+void az_launch_selfplay_begin(hipStream_t s, const AzTreeDev* d);
+void az_launch_env_step(hipStream_t s, const AzTreeDev* d, const int* actions, float* reward,
+                        uint8_t* done, int* illegal);
+void az_launch_env_reset(hipStream_t s, const AzTreeDev* d);
+void az_launch_env_export(hipStream_t s, const AzTreeDev* d, uint8_t* planes, uint8_t* mask);
+void az_launch_eval_hash(hipStream_t s, const uint8_t* planes, float* policy, float* value, int B, int A);
+}

@@ -1,0 +1,305 @@
+// tower.hip -- the ResNet policy/value tower (PVNetwork::forward, eval mode,
+// network.hpp:117-123) as hand-written gfx950 kernels.
+//
+//   az_stem_kernel    ConvBlock (network.hpp:15-17): 3x3 conv on the u8 planes,
+//                     BN folded, ReLU; exact fp32 VALU (K = 27 is too thin for MFMA)
+//   az_conv3x3_kernel ResBlock convolutions (network.hpp:32-38) as implicit GEMM
+//                     on v_mfma_f32_32x32x16_bf16: D[ch][pos] = sum_k W[ch][k] X[k][pos]
+//   az_heads_kernel   PolicyHead + ValueHead (network.hpp:51-60,75-83), fp32
+//
+// Activation layout in HBM: bf16 rows [guard + M_pad + guard][C_pad]; one row
+// per board position in a zero-padded (N+1)x(N+1) raster (column N and row N
+// of every board are kept zero), so every 3x3 tap of a real cell is a plain
+// row offset dy*(N+1)+dx and padding never needs a mask.  Boards are
+// consecutive, 256 rows form one output tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "az_tower.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TILE_M 256
+#define A_STRIDE 272            // 128 ch * 2 B + 16 B pad: conflict-free ds_read_b128
+#define B_STRIDE 144            // 64 k * 2 B + 16 B pad
+#define B_BUF_BYTES (128 * B_STRIDE)
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// ------------------------------------------------------------------- stem
+// One block per board.  w: [C_pad][27] fp32 (BN folded), bias [C_pad].
+extern "C" __global__ void __launch_bounds__(256)
+az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out,
+               const float* __restrict__ w, const float* __restrict__ bias,
+               int N, int C_pad, int Gd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int A = N * N, W = N + 1, P = W * W;
+    float* s_w = (float*)smem;                       // [C_pad][27]
+    float* s_b = s_w + C_pad * 27;                   // [C_pad]
+    uint8_t* s_in = (uint8_t*)(s_b + C_pad);         // [3][A]
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < C_pad * 27; i += 256) s_w[i] = w[i];
+    for (int i = threadIdx.x; i < C_pad; i += 256) s_b[i] = bias[i];
+    for (int i = threadIdx.x; i < 3 * A; i += 256) s_in[i] = planes[(size_t)b * 3 * A + i];
+    __syncthreads();
+    const int cpairs = C_pad / 2;
+    for (int idx = threadIdx.x; idx < P * cpairs; idx += 256) {
+        const int p = idx / cpairs, c = (idx % cpairs) * 2;
+        const int y = p / W, x = p % W;
+        float a0 = 0.f, a1 = 0.f;
+        if (y < N && x < N) {
+            a0 = s_b[c]; a1 = s_b[c + 1];
+            for (int ci = 0; ci < 3; ++ci)
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = y + ky - 1;
+                    if (yy < 0 || yy >= N) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = x + kx - 1;
+                        if (xx < 0 || xx >= N) continue;
+                        const float v = (float)s_in[ci * A + yy * N + xx];
+                        a0 += v * s_w[c * 27 + ci * 9 + ky * 3 + kx];
+                        a1 += v * s_w[(c + 1) * 27 + ci * 9 + ky * 3 + kx];
+                    }
+                }
+            a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f);
+        }
+        const unsigned pk = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+        *(unsigned*)(out + ((size_t)(Gd + b * P + p)) * C_pad + c) = pk;
+    }
+}
+
+// ---------------------------------------------------------------- conv 3x3
+// grid (M_pad/256, C_pad/128), 256 threads = 4 waves; wave w owns positions
+// [64w, 64w+64) of the tile and all 128 output channels of the column block:
+// 4x2 accumulator tiles of 32(ch) x 32(pos).
+// Weights arrive pre-packed as 16 KB chunks [nb][sc][tap][kc][n=128][k=64]
+// (bf16, BN scale folded), streamed through a double-buffered LDS stage;
+// the activation tile with its halo is staged once per 128-channel slab and
+// reused by all 9 taps.
+extern "C" __global__ void __launch_bounds__(256)
+az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                  const unsigned short* __restrict__ resid, const unsigned short* __restrict__ wpk,
+                  const float* __restrict__ bias, int C_pad, int M, int N, int Gd, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = N + 1, P = W * W;
+    const int a_rows = TILE_M + 2 * Gd;
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * TILE_M;
+    const int nb = blockIdx.y;
+    const int n_sc = C_pad / 128;
+    const int total = n_sc * 18;
+    const unsigned short* wbase = wpk + (size_t)nb * n_sc * 18 * (128 * 64);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 wreg[4];
+    auto load_w = [&](int c) {
+        const uint4* src = (const uint4*)(wbase + (size_t)c * (128 * 64));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wreg[p] = src[p * 256 + tid];
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = p * 256 + tid;
+            *(uint4*)(sB + buf * B_BUF_BYTES + (idx >> 3) * B_STRIDE + (idx & 7) * 16) = wreg[p];
+        }
+    };
+    auto stage_a = [&](int sc) {
+        for (int r = tid >> 4; r < a_rows; r += 16) {
+            const uint4 v = *(const uint4*)(in + (size_t)(m0 + r) * C_pad + sc * 128 + (tid & 15) * 8);
+            *(uint4*)(sA + r * A_STRIDE + (tid & 15) * 16) = v;
+        }
+    };
+
+    stage_a(0);
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+
+    const int posrow0 = Gd + 64 * wv + l31;            // LDS row of this lane's position, tile j adds 32
+    for (int c = 0; c < total; ++c) {
+        const int cc = c % 18;
+        const int tap = cc >> 1, kc = cc & 1;
+        const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
+        if (c + 1 < total) load_w(c + 1);
+        const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + kc * 128 + h * 16;
+        const unsigned char* bB = sB + (c & 1) * B_BUF_BYTES + l31 * B_STRIDE + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 xb[2], wa[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xb[j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8*)(bB + i * 32 * B_STRIDE + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xb[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < total) {
+            if ((c + 1) % 18 == 0) {                   // next 128-channel slab of the input
+                __syncthreads();
+                stage_a((c + 1) / 18);
+            }
+            store_w((c + 1) & 1);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: + bias (+ residual), ReLU, zero the padding raster, bf16 store
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + 64 * wv + 32 * j + l31;
+        const int p = m % P;
+        const bool real = m < M && (p / W) < N && (p % W) < N;
+        const size_t rowoff = (size_t)(Gd + m) * C_pad + nb * 128 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cch = 32 * i + 8 * q;
+                const float4 bv = *(const float4*)(bias + nb * 128 + cch + 4 * h);
+                float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
+                float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
+                if (resid) {
+                    const uint2 rv = *(const uint2*)(resid + rowoff + cch);
+                    v0 += bf2f((unsigned short)(rv.x & 0xFFFFu)); v1 += bf2f((unsigned short)(rv.x >> 16));
+                    v2 += bf2f((unsigned short)(rv.y & 0xFFFFu)); v3 += bf2f((unsigned short)(rv.y >> 16));
+                }
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                uint2 o = make_uint2(0u, 0u);
+                if (real) {
+                    o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                    o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                }
+                *(uint2*)(out + rowoff + cch) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------- heads
+// One block per board.  PolicyHead: 1x1 conv -> softmax over the N*N cells.
+// ValueHead: 1x1 conv -> BN(1) -> ReLU -> fc1 (N*N -> 64) -> ReLU -> fc2 -> softmax*2-1.
+// hp layout (fp32): wp[C_pad], wv[C_pad], {bp, bv (BN folded into wv/bv)}, then
+// fc1w [64][A], fc1b [64], fc2w [2][64], fc2b [2].
+extern "C" __global__ void __launch_bounds__(256)
+az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ hp,
+                float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int A = N * N, W = N + 1, P = W * W;
+    float* s_logit = (float*)smem;                   // [A]
+    float* s_u = s_logit + A;                        // [A]
+    float* s_red = s_u + A;                          // [256]
+    float* s_f1 = s_red + 256;                       // [64]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* wp = hp;
+    const float* wvv = hp + C_pad;
+    const float bp = hp[2 * C_pad], bvv = hp[2 * C_pad + 1];
+    const float* fc1w = hp + 2 * C_pad + 2;
+    const float* fc1b = fc1w + 64 * A;
+    const float* fc2w = fc1b + 64;
+    const float* fc2b = fc2w + 128;
+
+    for (int a = tid; a < A; a += 256) {
+        const int y = a / N, xx = a % N;
+        const unsigned short* row = x + ((size_t)(Gd + b * P + y * W + xx)) * C_pad;
+        float sp = 0.f, sv = 0.f;
+        for (int c = 0; c < C_pad; c += 8) {
+            const uint4 v = *(const uint4*)(row + c);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float lo = bf2f((unsigned short)(u[t] & 0xFFFFu)), hi = bf2f((unsigned short)(u[t] >> 16));
+                sp += lo * wp[c + 2 * t] + hi * wp[c + 2 * t + 1];
+                sv += lo * wvv[c + 2 * t] + hi * wvv[c + 2 * t + 1];
+            }
+        }
+        s_logit[a] = sp + bp;
+        s_u[a] = fmaxf(sv + bvv, 0.f);
+    }
+    __syncthreads();
+    // softmax over the A cells
+    float mx = -3.4e38f;
+    for (int a = tid; a < A; a += 256) mx = fmaxf(mx, s_logit[a]);
+    s_red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]); __syncthreads(); }
+    mx = s_red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int a = tid; a < A; a += 256) { const float e = expf(s_logit[a] - mx); s_logit[a] = e; sum += e; }
+    s_red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
+    sum = s_red[0];
+    for (int a = tid; a < A; a += 256) policy[(size_t)b * A + a] = s_logit[a] / sum;
+    // value: fc1 with 4 threads per output
+    {
+        const int o = tid >> 2, part = tid & 3;
+        float s = 0.f;
+        for (int a = part; a < A; a += 4) s += fc1w[o * A + a] * s_u[a];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (part == 0) s_f1[o] = fmaxf(s + fc1b[o], 0.f);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float z0 = fc2w[tid] * s_f1[tid], z1 = fc2w[64 + tid] * s_f1[tid];
+        for (int o = 32; o > 0; o >>= 1) { z0 += __shfl_xor(z0, o, 64); z1 += __shfl_xor(z1, o, 64); }
+        if (tid == 0) {
+            z0 += fc2b[0]; z1 += fc2b[1];
+            const float m2 = fmaxf(z0, z1);
+            const float e0 = expf(z0 - m2), e1 = expf(z1 - m2);
+            value[2 * b] = e0 / (e0 + e1) * 2.f - 1.f;
+            value[2 * b + 1] = e1 / (e0 + e1) * 2.f - 1.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------ host launchers
+static inline size_t conv_smem(int Gd) { return (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * B_BUF_BYTES; }
+
+extern "C" int az_tower_configure(void) {
+    hipError_t e = hipFuncSetAttribute((const void*)az_conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)az_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return (int)e;
+}
+
+extern "C" void az_launch_stem(hipStream_t s, const uint8_t* planes, unsigned short* out, const float* w,
+                               const float* bias, int B, int N, int C_pad, int Gd) {
+    const size_t sm = (size_t)C_pad * 28 * 4 + 3 * N * N + 16;
+    hipLaunchKernelGGL(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, w, bias, N, C_pad, Gd);
+}
+
+extern "C" void az_launch_conv3x3(hipStream_t s, const unsigned short* in, unsigned short* out,
+                                  const unsigned short* resid, const unsigned short* wpk, const float* bias,
+                                  int C_pad, int M, int N, int Gd, int relu) {
+    const int tiles = (M + TILE_M - 1) / TILE_M;
+    hipLaunchKernelGGL(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
+                       in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
+}
+
+extern "C" void az_launch_heads(hipStream_t s, const unsigned short* x, const float* hp, float* policy,
+                                float* value, int B, int N, int C_pad, int Gd) {
+    const size_t sm = (size_t)(2 * N * N + 256 + 64) * 4;
+    hipLaunchKernelGGL(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd);
+}

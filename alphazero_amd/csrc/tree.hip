@@ -1,0 +1,702 @@
+// tree.hip -- lockstep environment + MCTS kernels, one game (one tree) per
+// 64-lane wavefront, trees in flat HBM arenas.
+//
+// Restates, for nthreads = 1 and bit-exact visit statistics:
+//   MCTS::__select_and_eval / __choose / Node::ucb  (mcts.hpp:211-237,350-381; node.hpp:47-55)
+//   MCTS::_eval / _append_children                   (mcts.hpp:240-321,425-455)
+//   MCTS::__backup                                   (mcts.hpp:323-346)
+//   MCTS::__make_root / find                         (mcts.hpp:385-421; node.hpp:83-102)
+//   MCTS::search_probs output policy                 (mcts.hpp:136-146)
+//   generate.cpp's per-move / per-game loop          (generate.cpp:72-120)
+//   Env::step / possible_actions / get_board         (call sites mcts.hpp:251-271,427)
+// Built with -ffp-contract=off: every float/double expression keeps the
+// reference's evaluation order and promotions.
+#include "az_dev.h"
+
+#define AZ_WAVE 64
+#define AZ_CELLS_MAX 512
+
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << threadIdx.x) - 1ull;
+}
+
+// ---------------------------------------------------------------- env rules
+// K-in-a-row through the stone just placed at `action`: lanes 0..4*(2K-1)-1
+// each test one cell of one of the four lines, one ballot gathers them.
+__device__ bool az_win_check(const uint8_t* s_cells, int N, int K, int action, int stone) {
+    const int span = 2 * K - 1;
+    const int l = threadIdx.x;
+    bool hit = false;
+    if (l < 4 * span) {
+        const int dir = l / span, off = l % span - (K - 1);
+        const int dy = dir == 0 ? 0 : 1;
+        const int dx = dir == 0 ? 1 : (dir == 1 ? 0 : (dir == 2 ? 1 : -1));
+        const int y = action / N + off * dy, x = action % N + off * dx;
+        hit = y >= 0 && y < N && x >= 0 && x < N && s_cells[y * N + x] == stone;
+    }
+    const unsigned long long m = __ballot(hit);
+    bool win = false;
+    for (int d = 0; d < 4; ++d) {
+        const unsigned bits = (unsigned)(m >> (d * span)) & ((1u << span) - 1u);
+        int run = 1;
+        for (int s = 1; s < K; ++s) { if ((bits >> (K - 1 + s)) & 1u) ++run; else break; }
+        for (int s = 1; s < K; ++s) { if ((bits >> (K - 1 - s)) & 1u) ++run; else break; }
+        win = win || run >= K;
+    }
+    return win;
+}
+
+__device__ void az_write_planes(const AzTreeDev& d, int g, const uint8_t* s_cells, int to_move) {
+    uint8_t* pl = d.leaf_planes + (size_t)g * 3 * d.A;
+    for (int i = threadIdx.x; i < d.A; i += AZ_WAVE) {
+        const uint8_t c = s_cells[i];
+        pl[i] = c == 1;
+        pl[d.A + i] = c == 2;
+        pl[2 * d.A + i] = (uint8_t)to_move;
+    }
+}
+
+// ------------------------------------------------------- Dirichlet on device
+// util.h:42-58: gamma(alpha) draws, double sum, divide.  Marsaglia-Tsang with
+// the alpha+1 boost (the algorithm std::gamma_distribution uses); counter-based
+// uniforms.  Only the distribution is defined by the reference (random_device).
+__device__ float az_gamma_draw(unsigned long long seed, unsigned stream, unsigned base, float alpha) {
+    const float a1 = alpha + 1.0f;
+    const float dd = a1 - 1.0f / 3.0f;
+    const float cc = 1.0f / sqrtf(9.0f * dd);
+    float gv = dd;
+    unsigned r[4];
+    for (int it = 0; it < 16; ++it) {
+        az_philox4(seed, stream, base + (unsigned)it, r);
+        const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u3 = ((float)(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float x = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+        float v = 1.0f + cc * x;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        if (logf(u3) < 0.5f * x * x + dd - dd * v + dd * logf(v)) { gv = dd * v; break; }
+    }
+    az_philox4(seed, stream, base + 16u, r);
+    const float u4 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return gv * powf(u4, 1.0f / alpha);
+}
+
+__device__ void az_device_noise(const AzTreeDev& d, int g, int count) {
+    float* nz = d.noise + (size_t)g * d.A;
+    const unsigned ctr = d.noise_ctr[g];
+    const unsigned stream = 0x80000000u | (unsigned)(d.slot_base + g);
+    double part = 0.0;
+    for (int k = threadIdx.x; k < count; k += AZ_WAVE) {
+        const float x = az_gamma_draw(d.seed, stream, (ctr * 512u + (unsigned)k) * 32u, 0.05f);
+        nz[k] = x;
+        part += (double)x;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, AZ_WAVE);
+    __syncthreads();
+    for (int k = threadIdx.x; k < count; k += AZ_WAVE)
+        nz[k] = part > 0.0 ? (float)((double)nz[k] / part) : 1.0f / (float)count;
+    if (threadIdx.x == 0) d.noise_ctr[g] = ctr + 1u;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------ re-root (find)
+// Copies the subtree under `target` into the other arena in BFS order so the
+// new root is node 0 (the reference just drops the shared_ptr to the old
+// root, mcts.hpp:417-420).  Returns false if the arena bookkeeping is corrupt.
+__device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n, int* s_queue) {
+    const int ar = uni(d.arena[g]);
+    const AzEdge* E0 = d.edges[ar] + (size_t)g * d.edge_cap;
+    const uint16_t* A0 = d.eact[ar] + (size_t)g * d.edge_cap;
+    const int2* N0 = d.nodes[ar] + (size_t)g * d.node_cap;
+    AzEdge* E1 = d.edges[ar ^ 1] + (size_t)g * d.edge_cap;
+    uint16_t* A1 = d.eact[ar ^ 1] + (size_t)g * d.edge_cap;
+    int2* N1 = d.nodes[ar ^ 1] + (size_t)g * d.node_cap;
+    if (threadIdx.x == 0) s_queue[0] = target;
+    __syncthreads();
+    int new_count = 1, new_edges = 0;
+    for (int i = 0; i < new_count; ++i) {
+        const int old = uni(s_queue[i]);
+        const int2 nd = N0[old];
+        const int fe = uni(nd.x), ne = uni(nd.y);
+        if (threadIdx.x == 0) N1[i] = make_int2(new_edges, ne);
+        for (int c = 0; c < ne; c += AZ_WAVE) {
+            const int k = c + threadIdx.x;
+            const bool valid = k < ne;
+            AzEdge e = {0.f, 0, 0.f, -1};
+            uint16_t act = 0;
+            if (valid) { e = E0[fe + k]; act = A0[fe + k]; }
+            const bool has = valid && e.child >= 0;
+            const unsigned long long m = __ballot(has);
+            if (has) {
+                const int idx = new_count + __popcll(m & lanemask_lt());
+                s_queue[idx] = e.child;
+                e.child = idx;
+            }
+            if (valid) { E1[new_edges + k] = e; A1[new_edges + k] = act; }
+            new_count += __popcll(m);
+        }
+        new_edges += ne;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        d.arena[g] = ar ^ 1;
+        d.n_nodes[g] = new_count;
+        d.n_edges[g] = new_edges;
+        d.root_n[g] = target_n;
+        const int hl = d.hist_len[g];
+        for (int t = 0; t < hl; ++t) d.root_hist[(size_t)g * d.A + t] = d.hist[(size_t)g * d.A + t];
+        d.root_hist_len[g] = hl;
+    }
+    __syncthreads();
+}
+
+__device__ void az_drop_tree(const AzTreeDev& d, int g) {
+    if (threadIdx.x == 0) { d.root_hist_len[g] = -1; d.n_nodes[g] = 0; d.n_edges[g] = 0; d.root_n[g] = 0; }
+    __syncthreads();
+}
+
+// find() + the reuse rule of __make_root for the current env history.
+// returns 1 if the position is searchable, 0 if the root is a finished game.
+__device__ int az_make_root(const AzTreeDev& d, int g, int* s_queue) {
+    const int hl = uni(d.hist_len[g]);
+    const int rhl = uni(d.root_hist_len[g]);
+    if (uni(d.game_over[g])) { az_drop_tree(d, g); return 0; }
+    if (rhl < 0) return 1;
+    if (hl < rhl) { az_drop_tree(d, g); return 1; }                    // node.hpp:86
+    const uint16_t* H = d.hist + (size_t)g * d.A;
+    const uint16_t* RH = d.root_hist + (size_t)g * d.A;
+    bool mism = false;
+    for (int t = threadIdx.x; t < rhl; t += AZ_WAVE) mism = mism || H[t] != RH[t];
+    if (__ballot(mism)) { az_drop_tree(d, g); return 1; }              // node.hpp:89-90
+    if (hl == rhl) return 1;                                           // target == root: keep accumulating
+    const int ar = uni(d.arena[g]);
+    const AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
+    const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
+    const int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
+    int node = 0, tn = 0;
+    for (int t = rhl; t < hl; ++t) {                                   // node.hpp:93-100
+        const int action = H[t];
+        const int2 nd = ND[node];
+        const int fe = uni(nd.x), ne = uni(nd.y);
+        int found = -1;
+        for (int k = threadIdx.x; k < ne; k += AZ_WAVE)
+            if (EA[fe + k] == action) found = k;
+        for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o, AZ_WAVE));
+        found = uni(found);
+        if (found < 0) { az_drop_tree(d, g); return 1; }
+        const AzEdge e = E[fe + found];
+        const int child = uni(e.child);
+        // a never-visited stub has no state: searching from it is undefined in
+        // the reference; a terminal child cannot be current while !game_over
+        if (child < 0) { az_drop_tree(d, g); return 1; }
+        node = child;
+        tn = uni(e.n);
+    }
+    az_reroot(d, g, node, tn, s_queue);
+    return 1;
+}
+
+// -------------------------------------------------------------- apply phase
+// Consumes the evaluation of the previous round: expand (+Dirichlet at a
+// fresh root) and back up.
+__device__ void az_apply(const AzTreeDev& d, int g, uint8_t* s_cells) {
+    const int pend = uni(d.pending[g]);
+    if (pend == AZ_PEND_NONE) return;
+    const int A = d.A;
+    const int ar = uni(d.arena[g]);
+    AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
+    uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
+    int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
+    const int plen = uni(d.path_len[g]);
+    const int* path = d.path + (size_t)g * d.path_cap;
+    const int rt = uni(d.to_move[g]);
+    const int hl = uni(d.hist_len[g]);
+
+    if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
+        // the leaf position = root position + the moves along the path
+        if (threadIdx.x == 0)
+            for (int t = 0; t < plen; ++t) s_cells[EA[path[t]]] = (uint8_t)((rt ^ (t & 1)) + 1);
+        __syncthreads();
+        const int nn = uni(d.n_nodes[g]), ne0 = uni(d.n_edges[g]);
+        const int legal = A - (hl + plen);
+        if (nn >= d.node_cap || ne0 + legal > d.edge_cap) {
+            if (threadIdx.x == 0) { d.err[g] = 1; d.status[g] = AZ_ST_IDLE; d.pending[g] = AZ_PEND_NONE; }
+            __syncthreads();
+            return;
+        }
+        const bool is_root = pend == AZ_PEND_ROOT;
+        if (is_root && d.noise_mode == 1) az_device_noise(d, g, legal);
+        const float* pol = d.policy + (size_t)g * A;
+        const float* nz = d.noise + (size_t)g * A;
+        int base = 0;
+        for (int c = 0; c < A; c += AZ_WAVE) {                          // mcts.hpp:438-454
+            const int cell = c + threadIdx.x;
+            const bool lg = cell < A && s_cells[cell] == 0;
+            const unsigned long long m = __ballot(lg);
+            if (lg) {
+                const int k = base + __popcll(m & lanemask_lt());
+                float prior = pol[cell];
+                if (is_root)                                            // mcts.hpp:445 (double literals)
+                    prior = (float)(0.75 * (double)prior + 0.25 * (double)nz[k]);
+                AzEdge e = {prior, 0, 0.f, -1};
+                E[ne0 + k] = e;
+                EA[ne0 + k] = (uint16_t)cell;
+            }
+            base += __popcll(m);
+        }
+        if (threadIdx.x == 0) {
+            ND[nn] = make_int2(ne0, base);
+            d.n_nodes[g] = nn + 1;
+            d.n_edges[g] = ne0 + base;
+            if (!is_root) E[path[plen - 1]].child = nn;                 // leaf->add (mcts.hpp:316)
+            atomicMax(&d.counters[6], (unsigned long long)(nn + 1));
+            atomicMax(&d.counters[7], (unsigned long long)(ne0 + base));
+        }
+        __syncthreads();
+        // restore the root position in LDS
+        if (threadIdx.x == 0)
+            for (int t = 0; t < plen; ++t) s_cells[EA[path[t]]] = 0;
+        __syncthreads();
+    }
+    if (pend == AZ_PEND_ROOT) {                                         // mcts.hpp:412-413
+        if (threadIdx.x == 0) {
+            d.root_n[g] = 1;
+            for (int t = 0; t < hl; ++t) d.root_hist[(size_t)g * A + t] = d.hist[(size_t)g * A + t];
+            d.root_hist_len[g] = hl;
+        }
+    } else {                                                            // __backup, mcts.hpp:328-345
+        const float* res = pend == AZ_PEND_TERMINAL ? d.pend_result + 2 * g : d.value + 2 * g;
+        const float r0 = res[0], r1 = res[1];
+        const float vl = d.vl;
+        for (int t = threadIdx.x; t < plen; t += AZ_WAVE) {
+            AzEdge* e = &E[path[t]];
+            const int pp = rt ^ (t & 1);                                // parent->player
+            const float value = pp ? r1 : r0;
+            e->n = (int)((float)e->n + (1.f - vl));
+            e->v = e->v + (value + vl);
+        }
+        if (threadIdx.x == 0) {
+            d.root_n[g] = d.root_n[g] + 1;
+            d.sims_done[g] = d.sims_done[g] + 1;
+        }
+    }
+    if (threadIdx.x == 0) d.pending[g] = AZ_PEND_NONE;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------- select phase
+__device__ void az_select(const AzTreeDev& d, int g, uint8_t* s_cells) {
+    const int A = d.A, N = d.N;
+    const int rt = uni(d.to_move[g]);
+    const int hl = uni(d.hist_len[g]);
+    if (uni(d.root_hist_len[g]) < 0) {                                  // fresh root: evaluate the root board
+        az_write_planes(d, g, s_cells, rt);
+        if (threadIdx.x == 0) { d.pending[g] = AZ_PEND_ROOT; d.path_len[g] = 0; atomicAdd(&d.counters[1], 1ull); }
+        return;
+    }
+    const int ar = uni(d.arena[g]);
+    AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
+    const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
+    const int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
+    int* path = d.path + (size_t)g * d.path_cap;
+    const float vl = d.vl;
+    const float cpf = (float)d.c_puct_i;
+
+    int node = 0, par_n = uni(d.root_n[g]), player = rt, depth = 0, pend = AZ_PEND_NONE;
+    float t0 = 0.f, t1 = 0.f;
+    for (;;) {
+        const int2 nd = ND[node];
+        const int fe = uni(nd.x), ne = uni(nd.y);
+        const double s = sqrt((double)(par_n - 1));                     // node.hpp:54 sqrt(int) -> double
+        float best_val = -100.f;                                        // mcts.hpp:355
+        int best_k = -1;
+        for (int k = threadIdx.x; k < ne; k += AZ_WAVE) {
+            const AzEdge e = E[fe + k];
+            const float q = e.n != 0 ? __fdiv_rn(e.v, (float)e.n) : 0.f;
+            const float cp = cpf * e.p;                                 // int * float -> float
+            const double u = (double)cp * s / (double)(1 + e.n);
+            const float val = (float)((double)q + u);
+            if (val > best_val) { best_val = val; best_k = k; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {                              // first maximum in child order
+            const float ov = __shfl_xor(best_val, o, AZ_WAVE);
+            const int ok = __shfl_xor(best_k, o, AZ_WAVE);
+            if (ok >= 0 && (best_k < 0 || ov > best_val || (ov == best_val && ok < best_k))) { best_val = ov; best_k = ok; }
+        }
+        best_k = uni(best_k);
+        if (best_k < 0) {                                               // mcts.hpp:374-375 would throw
+            if (threadIdx.x == 0) { d.err[g] = 2; d.status[g] = AZ_ST_IDLE; }
+            return;
+        }
+        const int ei = fe + best_k;
+        AzEdge e = E[ei];
+        e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227
+        e.v = e.v - vl;
+        const int action = EA[ei];
+        if (threadIdx.x == 0) {
+            E[ei].n = e.n; E[ei].v = e.v;
+            path[depth] = ei;
+            s_cells[action] = (uint8_t)(player + 1);
+        }
+        __syncthreads();
+        const int mover = player;
+        player ^= 1;
+        depth++;
+        const int child = uni(e.child);
+        if (child >= 0) { node = child; par_n = uni(e.n); continue; }
+        if (child <= -2) {                                              // stored terminal reward, mcts.hpp:232-233
+            pend = AZ_PEND_TERMINAL;
+            t0 = child == -2 ? 1.f : (child == -3 ? -1.f : 0.f);
+            t1 = 0.f - t0;
+            break;
+        }
+        // stub: Env::step on the parent's state (mcts.hpp:261)
+        const bool win = az_win_check(s_cells, N, d.K, action, mover + 1);
+        const bool full = hl + depth == A;
+        if (win || full) {                                              // terminal_add, mcts.hpp:266-269
+            const int code = win ? (mover == 0 ? -2 : -3) : -4;
+            if (threadIdx.x == 0) E[ei].child = code;
+            pend = AZ_PEND_TERMINAL;
+            t0 = win ? (mover == 0 ? 1.f : -1.f) : 0.f;
+            t1 = 0.f - t0;
+        } else {
+            az_write_planes(d, g, s_cells, player);
+            pend = AZ_PEND_LEAF;
+        }
+        break;
+    }
+    if (threadIdx.x == 0) {
+        d.pending[g] = pend;
+        d.path_len[g] = depth;
+        if (pend == AZ_PEND_TERMINAL) { d.pend_result[2 * g] = t0; d.pend_result[2 * g + 1] = t1; }
+        else atomicAdd(&d.counters[1], 1ull);
+    }
+}
+
+// policy out = child n / root n (mcts.hpp:136-146)
+__device__ void az_emit_policy(const AzTreeDev& d, int g) {
+    const int A = d.A;
+    float* out = d.out_policy + (size_t)g * A;
+    for (int i = threadIdx.x; i < A; i += AZ_WAVE) out[i] = 0.f;
+    __syncthreads();
+    if (uni(d.root_hist_len[g]) < 0) return;
+    const int ar = uni(d.arena[g]);
+    const AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
+    const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
+    const int2 nd = (d.nodes[ar] + (size_t)g * d.node_cap)[0];
+    const float rn = (float)uni(d.root_n[g]);
+    for (int k = threadIdx.x; k < nd.y; k += AZ_WAVE)
+        out[EA[nd.x + k]] = __fdiv_rn((float)E[nd.x + k].n, rn);
+    __syncthreads();
+}
+
+// -------------------------------------------------------- self-play control
+// generate.cpp:84-118 for one slot after its search completed.
+__device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells, int* s_queue) {
+    const int A = d.A, N = d.N;
+    const int i = uni(d.move_idx[g]) + 1;                               // generate.cpp:82
+    const int rt = uni(d.to_move[g]);
+    // buffer.temporary_append(board, policy) (generate.cpp:85)
+    uint8_t* rc = d.row_cells + ((size_t)g * A + (i - 1)) * A;
+    float* rp = d.row_policy + ((size_t)g * A + (i - 1)) * A;
+    const float* op = d.out_policy + (size_t)g * A;
+    for (int c = threadIdx.x; c < A; c += AZ_WAVE) { rc[c] = s_cells[c]; rp[c] = op[c]; }
+    if (threadIdx.x == 0) d.row_tomove[(size_t)g * A + (i - 1)] = (uint8_t)rt;
+
+    const int ar = uni(d.arena[g]);
+    const AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
+    const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
+    const int2 nd = (d.nodes[ar] + (size_t)g * d.node_cap)[0];
+    const int fe = uni(nd.x), ne = uni(nd.y);
+    int chosen = -1;
+    if ((double)i < (double)d.avg_len[g] * 0.2) {                      // generate.cpp:88: sample ~ visits
+        unsigned part = 0;
+        for (int k = threadIdx.x; k < ne; k += AZ_WAVE) part += (unsigned)E[fe + k].n;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, AZ_WAVE);
+        const unsigned total = part;
+        unsigned r[4];
+        const unsigned ctr = d.sample_ctr[g];
+        az_philox4(d.seed, (unsigned)(d.slot_base + g), ctr, r);
+        const unsigned pick = (unsigned)(((unsigned long long)r[0] * total) >> 32);
+        unsigned carry = 0;
+        for (int c = 0; c < ne && chosen < 0; c += AZ_WAVE) {
+            const int k = c + threadIdx.x;
+            unsigned x = k < ne ? (unsigned)E[fe + k].n : 0u;
+            for (int o = 1; o < AZ_WAVE; o <<= 1) {                     // inclusive scan
+                const unsigned y = __shfl_up(x, o, AZ_WAVE);
+                if ((int)threadIdx.x >= o) x += y;
+            }
+            const bool hit = k < ne && carry + x > pick;
+            const unsigned long long m = __ballot(hit);
+            if (m) chosen = c + (__ffsll((long long)m) - 1);
+            carry += __shfl(x, AZ_WAVE - 1, AZ_WAVE);
+        }
+        if (threadIdx.x == 0) d.sample_ctr[g] = ctr + 1u;
+    } else {                                                            // generate.cpp:95: first arg-max
+        int bn = -1, bk = -1;
+        for (int k = threadIdx.x; k < ne; k += AZ_WAVE) {
+            const int n = E[fe + k].n;
+            if (n > bn) { bn = n; bk = k; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int on = __shfl_xor(bn, o, AZ_WAVE), ok = __shfl_xor(bk, o, AZ_WAVE);
+            if (ok >= 0 && (bk < 0 || on > bn || (on == bn && ok < bk))) { bn = on; bk = ok; }
+        }
+        chosen = bn > 0 ? bk : -1;
+    }
+    chosen = uni(chosen);
+    // all-zero policy: torch::argmax returns 0 (cannot happen once root n > 1)
+    const int action = chosen >= 0 ? EA[fe + chosen] : 0;
+    const int child = chosen >= 0 ? uni(E[fe + chosen].child) : -1;
+    const int child_n = chosen >= 0 ? uni(E[fe + chosen].n) : 0;
+
+    // env.step on the real game (generate.cpp:103)
+    const int hl = uni(d.hist_len[g]);
+    if (threadIdx.x == 0) {
+        s_cells[action] = (uint8_t)(rt + 1);
+        d.cells[(size_t)g * A + action] = (uint8_t)(rt + 1);
+        d.hist[(size_t)g * A + hl] = (uint16_t)action;
+        d.hist_len[g] = hl + 1;
+        d.to_move[g] = (uint8_t)(rt ^ 1);
+        atomicAdd(&d.counters[2], 1ull);
+    }
+    __syncthreads();
+    const bool win = az_win_check(s_cells, N, d.K, action, rt + 1);
+    const bool done = win || hl + 1 == A;
+    if (!done) {
+        if (threadIdx.x == 0) { d.move_idx[g] = i; d.sims_done[g] = 0; d.sims_target[g] = d.budget; }
+        __syncthreads();
+        if (child >= 0) az_reroot(d, g, child, child_n, s_queue); else az_drop_tree(d, g);
+        return;
+    }
+    // game over: buffer.send_reward(reward); agent.clear(); stats (generate.cpp:110-118)
+    const float r0 = win ? (rt == 0 ? 1.f : -1.f) : 0.f;
+    int base = -1;
+    if (threadIdx.x == 0) {
+        unsigned long long old = atomicAdd(&d.counters[4], 0ull);
+        for (;;) {
+            if (old + (unsigned long long)i > (unsigned long long)d.ring_cap) { atomicAdd(&d.counters[5], (unsigned long long)i); break; }
+            const unsigned long long prev = atomicCAS(&d.counters[4], old, old + (unsigned long long)i);
+            if (prev == old) { base = (int)old; break; }
+            old = prev;
+        }
+    }
+    base = __shfl(base, 0, AZ_WAVE);
+    if (base >= 0) {
+        for (int r = 0; r < i; ++r) {
+            const uint8_t* src_c = d.row_cells + ((size_t)g * A + r) * A;
+            const float* src_p = d.row_policy + ((size_t)g * A + r) * A;
+            uint8_t* dc = d.ring_cells + (size_t)(base + r) * A;
+            float* dp = d.ring_policy + (size_t)(base + r) * A;
+            for (int c = threadIdx.x; c < A; c += AZ_WAVE) { dc[c] = src_c[c]; dp[c] = src_p[c]; }
+            if (threadIdx.x == 0) {
+                d.ring_tomove[base + r] = d.row_tomove[(size_t)g * A + r];
+                d.ring_reward[2 * (size_t)(base + r)] = r0;
+                d.ring_reward[2 * (size_t)(base + r) + 1] = 0.f - r0;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        const long long gc = d.game_count[g] + 1;                       // generate.cpp:25-29
+        d.game_count[g] = gc;
+        const float al = d.avg_len[g];
+        d.avg_len[g] = al + ((float)i - al) / (float)gc;
+        atomicAdd(&d.counters[3], 1ull);
+        d.final_reward[2 * g] = r0; d.final_reward[2 * g + 1] = 0.f - r0;
+        // env.reset(), fresh search with the warm-up doubling (generate.cpp:75-77)
+        d.hist_len[g] = 0; d.to_move[g] = 0; d.move_idx[g] = 0;
+        d.sims_done[g] = 0; d.sims_target[g] = 2 * d.budget;
+    }
+    for (int c = threadIdx.x; c < A; c += AZ_WAVE) { d.cells[(size_t)g * A + c] = 0; s_cells[c] = 0; }
+    __syncthreads();
+    az_drop_tree(d, g);
+}
+
+// ------------------------------------------------------------------ kernels
+// One lockstep round.  phase_mask bit0: apply the pending evaluation,
+// bit1: advance (finish search / play move / select the next leaf).
+extern "C" __global__ void __launch_bounds__(AZ_WAVE)
+az_round_kernel(AzTreeDev d, int phase_mask, int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t* s_cells = smem;
+    int* s_queue = (int*)(smem + AZ_CELLS_MAX);
+    const int g = blockIdx.x;
+    if (uni(d.status[g]) != AZ_ST_RUN) return;
+    for (int c = threadIdx.x; c < d.A; c += AZ_WAVE) s_cells[c] = d.cells[(size_t)g * d.A + c];
+    __syncthreads();
+    if (phase_mask & 1) az_apply(d, g, s_cells);
+    if (!(phase_mask & 2)) return;
+    if (uni(d.status[g]) != AZ_ST_RUN) return;
+    if (uni(d.pending[g]) != AZ_PEND_NONE) return;                      // select already issued
+    if (uni(d.sims_done[g]) >= uni(d.sims_target[g])) {
+        az_emit_policy(d, g);
+        if (threadIdx.x == 0) atomicAdd(&d.counters[0], (unsigned long long)d.sims_done[g]);
+        if (mode == AZ_MODE_SEARCH) {
+            if (threadIdx.x == 0) d.status[g] = AZ_ST_IDLE;
+            return;
+        }
+        az_selfplay_move(d, g, s_cells, s_queue);
+    }
+    az_select(d, g, s_cells);
+}
+
+// search_probs entry: root reuse decision (mcts.hpp:121) for every game.
+extern "C" __global__ void __launch_bounds__(AZ_WAVE)
+az_begin_kernel(AzTreeDev d, int budget) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_queue = (int*)(smem + AZ_CELLS_MAX);
+    const int g = blockIdx.x;
+    const int ok = az_make_root(d, g, s_queue);
+    if (threadIdx.x == 0) {
+        d.sims_done[g] = 0;
+        // Q10: the loop body runs once even for budget <= 0 (mcts.hpp:161-174)
+        d.sims_target[g] = budget > 1 ? budget : 1;
+        d.pending[g] = AZ_PEND_NONE;
+        d.status[g] = ok ? AZ_ST_RUN : AZ_ST_IDLE;
+    }
+    if (!ok) {
+        float* out = d.out_policy + (size_t)g * d.A;
+        for (int i = threadIdx.x; i < d.A; i += AZ_WAVE) out[i] = 0.f;
+    }
+}
+
+extern "C" __global__ void az_selfplay_begin_kernel(AzTreeDev d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    d.status[g] = AZ_ST_RUN;
+    d.pending[g] = AZ_PEND_NONE;
+    d.sims_done[g] = 0;
+    d.sims_target[g] = 2 * d.budget;
+    d.move_idx[g] = 0;
+    d.avg_len[g] = 25.f;                                                // generate.cpp:69
+    d.game_count[g] = 0;
+    d.sample_ctr[g] = 0;
+    d.root_hist_len[g] = -1; d.n_nodes[g] = 0; d.n_edges[g] = 0; d.root_n[g] = 0;
+    d.hist_len[g] = 0; d.to_move[g] = 0; d.game_over[g] = 0;
+    for (int c = 0; c < d.A; ++c) d.cells[(size_t)g * d.A + c] = 0;
+}
+
+// Env::step for the real games (generate.cpp:103), batched.
+extern "C" __global__ void __launch_bounds__(AZ_WAVE)
+az_env_step_kernel(AzTreeDev d, const int* actions, float* reward, uint8_t* done, int* illegal) {
+    __shared__ uint8_t s_cells[AZ_CELLS_MAX];
+    const int g = blockIdx.x;
+    const int A = d.A;
+    const int action = uni(actions[g]);
+    if (threadIdx.x == 0) { reward[2 * g] = 0.f; reward[2 * g + 1] = 0.f; done[g] = d.game_over[g]; }
+    if (action < 0) return;
+    for (int c = threadIdx.x; c < A; c += AZ_WAVE) s_cells[c] = d.cells[(size_t)g * A + c];
+    __syncthreads();
+    if (action >= A || s_cells[action] != 0 || uni(d.game_over[g])) {
+        if (threadIdx.x == 0) atomicAdd(illegal, 1);
+        return;
+    }
+    const int mover = uni(d.to_move[g]);
+    const int hl = uni(d.hist_len[g]);
+    if (threadIdx.x == 0) {
+        s_cells[action] = (uint8_t)(mover + 1);
+        d.cells[(size_t)g * A + action] = (uint8_t)(mover + 1);
+        d.hist[(size_t)g * A + hl] = (uint16_t)action;
+        d.hist_len[g] = hl + 1;
+        d.to_move[g] = (uint8_t)(mover ^ 1);
+    }
+    __syncthreads();
+    const bool win = az_win_check(s_cells, d.N, d.K, action, mover + 1);
+    const bool over = win || hl + 1 == A;
+    if (threadIdx.x == 0) {
+        const float r0 = win ? (mover == 0 ? 1.f : -1.f) : 0.f;
+        reward[2 * g] = r0; reward[2 * g + 1] = 0.f - r0;
+        done[g] = over;
+        d.game_over[g] = over;
+        d.final_reward[2 * g] = r0; d.final_reward[2 * g + 1] = 0.f - r0;
+    }
+}
+
+extern "C" __global__ void az_env_reset_kernel(AzTreeDev d) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < d.A; c += blockDim.x) d.cells[(size_t)g * d.A + c] = 0;
+    if (threadIdx.x == 0) { d.to_move[g] = 0; d.hist_len[g] = 0; d.game_over[g] = 0; }
+}
+
+// Env::get_board for the real games: u8 planes [G,3,N,N]; legal mask [G,N,N].
+extern "C" __global__ void az_env_export_kernel(AzTreeDev d, uint8_t* planes, uint8_t* mask) {
+    const int g = blockIdx.x;
+    const int A = d.A;
+    const int tm = d.to_move[g];
+    for (int c = threadIdx.x; c < A; c += blockDim.x) {
+        const uint8_t v = d.cells[(size_t)g * A + c];
+        if (planes) {
+            planes[(size_t)g * 3 * A + c] = v == 1;
+            planes[(size_t)g * 3 * A + A + c] = v == 2;
+            planes[(size_t)g * 3 * A + 2 * A + c] = (uint8_t)tm;
+        }
+        if (mask) mask[(size_t)g * A + c] = v == 0 && !d.game_over[g];
+    }
+}
+
+// Integer-hash pseudo network (parity evaluator): one wave per board.
+extern "C" __global__ void __launch_bounds__(AZ_WAVE)
+az_eval_hash_kernel(const uint8_t* planes, float* policy, float* value, int A) {
+    const int g = blockIdx.x;
+    const uint8_t* pl = planes + (size_t)g * 3 * A;
+    unsigned long long H = 0;
+    for (int i = threadIdx.x; i < 3 * A; i += AZ_WAVE)
+        H ^= az_splitmix64((unsigned long long)i * 256ull + pl[i]);
+    for (int o = 32; o > 0; o >>= 1) H ^= __shfl_xor(H, o, AZ_WAVE);
+    unsigned sum = 0;
+    for (int i = threadIdx.x; i < A; i += AZ_WAVE) {
+        const unsigned long long r = (az_splitmix64(H + (unsigned long long)i + 1ull) >> 40) & 0xFFFFull;
+        sum += 1u + (unsigned)((r * r * r) >> 32);
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, AZ_WAVE);
+    const float fs = (float)sum;
+    for (int i = threadIdx.x; i < A; i += AZ_WAVE) {
+        const unsigned long long r = (az_splitmix64(H + (unsigned long long)i + 1ull) >> 40) & 0xFFFFull;
+        const unsigned w = 1u + (unsigned)((r * r * r) >> 32);
+        policy[(size_t)g * A + i] = __fdiv_rn((float)w, fs);
+    }
+    if (threadIdx.x == 0) {
+        const int t = (int)((az_splitmix64(H ^ 0xABCDEFull) >> 40) & 0xFFFFull);
+        const float v0 = __fdiv_rn((float)t - 32768.0f, 40000.0f);
+        value[2 * g] = v0;
+        value[2 * g + 1] = -v0;
+    }
+}
+
+// ------------------------------------------------------------ host launchers
+#include "az_tree.h"
+
+static inline size_t tree_smem(const AzTreeDev& d) { return AZ_CELLS_MAX + (size_t)d.node_cap * sizeof(int); }
+
+extern "C" int az_tree_configure(const AzTreeDev* d) {
+    const size_t sm = tree_smem(*d);
+    if (sm > 160 * 1024) return -1;
+    hipError_t e = hipFuncSetAttribute((const void*)az_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)az_begin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    return (int)e;
+}
+extern "C" void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode) {
+    hipLaunchKernelGGL(az_round_kernel, dim3(d->G), dim3(AZ_WAVE), tree_smem(*d), s, *d, phase_mask, mode);
+}
+extern "C" void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget) {
+    hipLaunchKernelGGL(az_begin_kernel, dim3(d->G), dim3(AZ_WAVE), tree_smem(*d), s, *d, budget);
+}
+extern "C" void az_launch_selfplay_begin(hipStream_t s, const AzTreeDev* d) {
+    hipLaunchKernelGGL(az_selfplay_begin_kernel, dim3((d->G + 63) / 64), dim3(64), 0, s, *d);
+}
+extern "C" void az_launch_env_step(hipStream_t s, const AzTreeDev* d, const int* actions, float* reward,
+                                   uint8_t* done, int* illegal) {
+    hipLaunchKernelGGL(az_env_step_kernel, dim3(d->G), dim3(AZ_WAVE), 0, s, *d, actions, reward, done, illegal);
+}
+extern "C" void az_launch_env_reset(hipStream_t s, const AzTreeDev* d) {
+    hipLaunchKernelGGL(az_env_reset_kernel, dim3(d->G), dim3(64), 0, s, *d);
+}
+extern "C" void az_launch_env_export(hipStream_t s, const AzTreeDev* d, uint8_t* planes, uint8_t* mask) {
+    hipLaunchKernelGGL(az_env_export_kernel, dim3(d->G), dim3(64), 0, s, *d, planes, mask);
+}
+extern "C" void az_launch_eval_hash(hipStream_t s, const uint8_t* planes, float* policy, float* value, int B, int A) {
+    hipLaunchKernelGGL(az_eval_hash_kernel, dim3(B), dim3(AZ_WAVE), 0, s, planes, policy, value, A);
+}

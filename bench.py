@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Self-play hot-path benchmark: MCTS simulations/s, whole job.
+
+One step = one lockstep round = one pass of the hot path (env step -> PUCT
+select -> tower evaluation -> expand -> backup) over G concurrent 15x15 gomoku
+games per GPU (BASELINE.json configs[2] sharded by game: 4096 games over 8
+GPUs = 512 per GPU; at N=1 the same 512-game shard).  Weak scaling: every rank
+owns its own games, there is no collective inside the timed region.
+
+    python bench.py --gpus 1 --steps 300 --warmup 40
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak of one MI355X
+
+
+def cpu_baseline(seconds, N, K, budget, nthreads):
+    """The reference's own MCTS/Evaluator/PVNetwork (compiled unmodified into
+    oracle/_ref/az_ref) running the generate.cpp loop on this host's cores."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "az_ref")
+    if os.path.exists(ref):
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        with tempfile.TemporaryDirectory() as d:
+            try:
+                out = subprocess.run([ref, "bench", str(N), str(K), str(nthreads), str(budget), str(seconds), d],
+                                     env=env, capture_output=True, text=True, timeout=seconds * 6 + 120).stdout
+                line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+                r = json.loads(line)
+                return {"value": r["sims_per_s"], "unit": "sims/s", "cores": int(r["torch_threads"]), "kind": "reference",
+                        "sample": "reference mcts.hpp+evaluator.hpp+network.hpp (libtorch CPU, NetConfig 2), generate.cpp loop, "
+                                  "%dx%d gomoku, nthreads=%d, batch 16, %d sims/move, %.0f s wall, %d sims, %d torch intra-op threads"
+                                  % (N, N, nthreads, budget, r["seconds"], r["sims"], r["torch_threads"])}
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("reference baseline failed (%r); falling back to the oracle port\n" % (e,))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import azo
+    from alphazero_amd import synth
+    Cs = synth.NETCONFIG2
+    tower = azo.Tower(N, 3, Cs, synth.make_blob(N, 3, Cs, 0))
+    m = azo.MCTS(N, K, 3.0, 3.0, "tower", tower)
+    t0 = time.time()
+    sims = 0
+    while time.time() - t0 < seconds:
+        m.search([], 4, None)
+        sims += 4
+    el = time.time() - t0
+    return {"value": sims / el, "unit": "sims/s", "cores": 1, "kind": "port",
+            "sample": "scalar C++ restatement, %dx%d, %d sims in %.1f s" % (N, N, sims, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--games", type=int, default=512, help="concurrent games per GPU")
+    ap.add_argument("--board", type=int, default=15)
+    ap.add_argument("--budget", type=int, default=800)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    from alphazero_amd import capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    N, K, G, budget = args.board, 5, args.games, args.budget
+    Cs = synth.NETCONFIG2
+    eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
+                      device=local_rank, game_slot_base=rank * G)
+    # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
+    nw = eng.weights_size()
+    if world > 1:
+        wt = torch.empty(nw, dtype=torch.float32, device="cuda")
+        if rank == 0:
+            wt.copy_(torch.from_numpy(synth.make_blob(N, 3, Cs, 0)))
+        dist.broadcast(wt, 0)
+        torch.cuda.synchronize()
+        eng.load_weights_dev(wt.data_ptr(), nw)
+    else:
+        eng.load_weights(synth.make_blob(N, 3, Cs, 0))
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.selfplay_begin(budget)
+    eng.selfplay_run(args.warmup)
+    eng.profile_enable(8)
+    barrier()
+    t0 = time.perf_counter()
+    eng.selfplay_run(args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    prof = eng.profile_read()
+    st = eng.stats()
+    if st["error_games"]:
+        raise SystemExit("tree arena overflow in %d games" % st["error_games"])
+
+    if rank == 0:
+        A = N * N
+        C = Cs[0]
+        sims = G * args.steps * world                     # one simulation per game per round
+        conv_flops = 2.0 * 9 * A * C * C * G               # real cells only (algorithmic)
+        conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
+        line = {
+            "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
+                                   "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
+                       "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world},
+            "moves_per_s": None,
+            "roofline": {"bound": "mfma", "kernel": "az_conv3x3_kernel", "achieved": conv_tflops,
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": None, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
+                         "flops_per_launch": conv_flops,
+                         "tree_round_avg_us": prof["tree_avg_us"]},
+        }
+        line["games_per_hour_est"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, N, K, budget, 16)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * az_hip.h -- C ABI of libazhip.so: the MI355X-native self-play hot path
+ * (env step -> PUCT select with virtual loss -> ResNet leaf evaluation ->
+ * expand -> backup) behind the reference's Env / MCTS / Evaluator / PVNetwork
+ * interfaces.  The reference has no FFI of its own; its boundary is the C++
+ * class API, so each entry point cites the reference member it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions: every function returns 0 on success or a negative AZ_E_* code
+ * and records a message readable with az_last_error() (the reference throws
+ * std::runtime_error: node.hpp:50-53, mcts.hpp:374-375, util.h:69-82).  No
+ * exception crosses this boundary.  The caller owns every host buffer; the
+ * library owns all device memory.  One context per GPU; a context is not
+ * thread-safe, distinct contexts may be driven from distinct host threads.
+ * G games advance in lockstep: one round = one simulation per game
+ * (= MCTS::__simulate_once at nthreads=1, mcts.hpp:183-208) with the G leaf
+ * boards evaluated as one batch (the Evaluator's role, evaluator.hpp:80-124).
+ */
+#ifndef AZ_HIP_H
+#define AZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_OK            0
+#define AZ_E_ARG        -1   /* bad argument */
+#define AZ_E_HIP        -2   /* HIP runtime error (message has the call) */
+#define AZ_E_CAPACITY   -3   /* a tree arena overflowed */
+#define AZ_E_STATE      -4   /* call not valid in the current state */
+#define AZ_E_NOWEIGHTS  -5   /* tower used before az_load_weights */
+
+#define AZ_MAX_LAYERS 64
+
+/* eval_mode */
+#define AZ_EVAL_TOWER    0   /* PVNetwork forward on the device (network.hpp) */
+#define AZ_EVAL_HASH     1   /* integer-hash pseudo network, bit-reproducible on CPU */
+#define AZ_EVAL_EXTERNAL 2   /* caller evaluates leaves (az_search_select/apply) */
+/* noise_mode */
+#define AZ_NOISE_EXPLICIT 0  /* Dirichlet noise from az_set_noise */
+#define AZ_NOISE_DEVICE   1  /* drawn on the device, alpha = 0.05 (util.h:42) */
+/* precision of the tower's 3x3 convolutions */
+#define AZ_PREC_BF16     0   /* bf16 operands, fp32 accumulate (MFMA) */
+#define AZ_PREC_BF16X3   1   /* split-bf16 (hi+lo), ~fp32 accuracy, 3 MFMA passes */
+
+typedef struct az_ctx az_ctx;
+
+typedef struct az_config {
+    int   device;                 /* HIP device ordinal */
+    int   N;                      /* board side: Env::get_board_size (mcts.hpp:51) */
+    int   K;                      /* stones in a row that win (3 tictactoe, 5 gomoku) */
+    int   G;                      /* concurrent games on this GPU */
+    int   n_Cs;                   /* length of Cs; num_res = n_Cs-1 (network.hpp:105) */
+    int   Cs[AZ_MAX_LAYERS];      /* NetConfig::resblocks() (netconfig.hpp:19-22) */
+    float vl;                     /* MCTS ctor vl_ (mcts.hpp:41) */
+    float c_puct;                 /* MCTS ctor c_puct_; truncated to int by Node::ucb (node.hpp:47) */
+    int   node_cap;               /* expanded nodes per tree arena, 0 = 4*max_budget+64 */
+    int   max_budget;             /* largest iter_budget that will be requested */
+    int   eval_mode;
+    int   noise_mode;
+    int   precision;
+    uint64_t seed;                /* counter-based generator seed (sampling, device noise) */
+    int   game_slot_base;         /* global index of this context's game 0 (multi-GPU sharding) */
+} az_config;
+
+typedef struct az_stats {
+    int64_t sims;                 /* completed simulations (MCTS::count, mcts.hpp:170) */
+    int64_t evals;                /* leaf/root boards submitted to the evaluator (evaluator.hpp:150-165) */
+    int64_t rounds;               /* lockstep rounds executed */
+    int64_t moves;                /* self-play moves played */
+    int64_t games;                /* self-play games finished (generate.cpp:115) */
+    int64_t replay_rows;          /* rows currently waiting in the replay ring */
+    int64_t replay_dropped;       /* rows dropped because the ring was full */
+    int32_t max_nodes;            /* high-water mark of expanded nodes in any tree */
+    int32_t max_edges;
+    int32_t error_games;          /* games whose arena overflowed */
+} az_stats;
+
+const char* az_last_error(void);
+
+/* MCTS<Env>::MCTS + Evaluator<Env>::Evaluator (mcts.hpp:41-73, evaluator.hpp:48-77):
+ * allocates all device state for G games and the tower. */
+int az_ctx_create(az_ctx** out, const az_config* cfg);
+int az_ctx_destroy(az_ctx*);                       /* ~MCTS / ~Evaluator (mcts.hpp:80-87) */
+int az_sync(az_ctx*);                              /* wait for the context's stream */
+void* az_stream(az_ctx*);                          /* the hipStream_t all work is issued on */
+
+/* load_network (util.h:60-105) without the file: flat fp32 blob in module
+ * registration order (see alphazero_amd/synth.py blob_layout); BatchNorm is
+ * folded here.  Host pointer, or a device pointer with the _dev variant
+ * (used after an RCCL broadcast). */
+size_t az_weights_size(const az_ctx*);
+int az_load_weights(az_ctx*, const float* blob, size_t n_floats);
+int az_load_weights_dev(az_ctx*, const float* blob_dev, size_t n_floats);
+
+/* Env::reset (generate.cpp:75), Env::step (mcts.hpp:251,261; generate.cpp:103),
+ * Env::get_board (mcts.hpp:271), Env::possible_actions (mcts.hpp:427), batched
+ * over the G games.  actions[g] = y*N+x, or -1 to leave game g untouched.
+ * reward f32 [G,2] by absolute player, done u8 [G]. */
+int az_env_reset(az_ctx*);
+int az_env_step(az_ctx*, const int32_t* actions, float* reward, uint8_t* done);
+int az_env_boards(az_ctx*, uint8_t* planes /* [G,3,N,N] */);
+int az_env_legal_mask(az_ctx*, uint8_t* mask /* [G,N,N] */);
+int az_env_set(az_ctx*, const uint8_t* cells /* [G,N*N] 0/1/2 */, const uint8_t* to_move /* [G] */);
+
+/* PVNetwork::forward (network.hpp:117-123) in eval mode as driven by
+ * Evaluator::run (evaluator.hpp:113-117): boards u8 [B,3,N,N] ->
+ * policy f32 [B,N*N] (softmax probabilities), value f32 [B,2]. */
+int az_tower_forward(az_ctx*, const uint8_t* boards, int B, float* policy, float* value);
+int az_tower_forward_dev(az_ctx*, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev);
+
+/* util.h:42-58 made an input: noise f32 [G,N*N], used in legal-action order
+ * for every freshly created root (mcts.hpp:432-446). */
+int az_set_noise(az_ctx*, const float* noise);
+
+/* MCTS::search_probs (mcts.hpp:105-155) for all G games from their current
+ * env states, including root reuse (mcts.hpp:385-421): out f32 [G,N*N]. */
+int az_search(az_ctx*, int iter_budget, float* out_policy);
+/* The same search with the evaluator outside: begin, then alternate
+ * select (planes u8 [G,3,N,N]; pending i32 [G]: 0 nothing, 1 root, 2 leaf,
+ * 3 terminal) and apply (policy f32 [G,N*N], value f32 [G,2]) until select
+ * returns *n_running == 0, then read the result. */
+int az_search_begin(az_ctx*, int iter_budget);
+int az_search_select(az_ctx*, uint8_t* planes, int32_t* pending, int* n_running);
+int az_search_apply(az_ctx*, const float* policy, const float* value);
+int az_search_result(az_ctx*, float* out_policy, int32_t* root_n /* [G] or NULL */);
+int az_tree_clear(az_ctx*);                        /* MCTS::clear (mcts.hpp:462-465) */
+
+/* Parity introspection: raw arena of game g.  edges are {p,n,v,child}; child
+ * >= 0 expanded node id, -1 stub, -2/-3/-4 terminal (p0 wins / p1 wins / draw).
+ * Call with cap 0 to size.  Node 0 is the root. */
+int az_tree_dump(az_ctx*, int game, int node_cap, int edge_cap, int32_t* n_nodes, int32_t* n_edges,
+                 int32_t* node_first, int32_t* node_count,
+                 float* edge_p, int32_t* edge_n, float* edge_v, int32_t* edge_child, int32_t* edge_action);
+
+/* generate.cpp:72-120 on the device for all G slots: runs `rounds` lockstep
+ * rounds of self-play (search -> record row -> sample/argmax -> step -> on
+ * game end attach rewards, restart).  Rows accumulate in a device ring. */
+int az_selfplay_begin(az_ctx*, int iter_budget);
+int az_selfplay_run(az_ctx*, int rounds);
+/* Drain finished rows: cells u8 [n,N*N] (0/1/2), to_move u8 [n], policy f32
+ * [n,N*N], reward f32 [n,2] (replay.hpp:56-60,62-79 before symmetry expansion).
+ * Returns the number of rows copied (<= cap) or a negative error. */
+int az_replay_drain(az_ctx*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
+int az_get_stats(az_ctx*, az_stats*);
+
+/* Measurement hook (no counterpart in the reference, whose only timers are the
+ * verbosity-3 chrono buckets of mcts.hpp:187-201): HIP events on the context's
+ * stream around every 3x3-convolution launch and every tree-round launch of
+ * each `every`-th evaluator call; every = 0 switches sampling off. */
+int az_profile_enable(az_ctx*, int every);
+int az_profile_read(az_ctx*, double* conv_avg_us, int64_t* conv_launches,
+                    double* tree_avg_us, int64_t* tree_launches);
+
+/* replay.hpp:80-112: the 8 dihedral variants of one row in emission order,
+ * states u8 [8,3,N,N], policies f32 [8,N,N] (host-side helper). */
+int az_replay_symmetries(int N, const uint8_t* cells, int to_move, const float* policy,
+                         uint8_t* states_out, float* policies_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZ_HIP_H */
