@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,6 +40,8 @@ struct az_ctx {
     unsigned short *actX = nullptr, *actH = nullptr;      // [rows][C_pad] bf16
     size_t act_rows = 0;
     float *stem_w = nullptr, *stem_b = nullptr;           // [C_pad][27], [C_pad]
+    unsigned short* stem_wbf = nullptr;                   // [128][32] bf16, fused path
+    bool fused = false;                                   // whole tower in one launch
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
     float* head_p = nullptr;
@@ -164,6 +167,8 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
         AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
         AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27)); AZCHK(dalloc(c, &c->stem_b, c->C_pad));
+        AZCHK(dalloc(c, &c->stem_wbf, (size_t)128 * 32));
+        c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED");
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
         AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
         AZCHK(dalloc(c, &c->conv_b, (size_t)2 * c->num_res * c->C_pad));
@@ -187,6 +192,7 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     return AZ_OK;
 }
 
+extern "C" int az_tower_is_fused(const az_ctx* c) { return c->fused ? 1 : 0; }
 extern "C" int az_sync(az_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return AZ_OK; }
 extern "C" void* az_stream(az_ctx* c) { return (void*)c->stream; }
 
@@ -231,6 +237,12 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     }
     HIPCHK(hipMemcpy(c->stem_w, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->stem_b, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
+    if (c->fused) {
+        std::vector<unsigned short> swb((size_t)128 * 32, 0);
+        for (int co = 0; co < C; ++co)
+            for (int k = 0; k < 27; ++k) swb[(size_t)co * 32 + k] = host_f2bf(sw[(size_t)co * 27 + k]);
+        HIPCHK(hipMemcpy(c->stem_wbf, swb.data(), swb.size() * 2, hipMemcpyHostToDevice));
+    }
     // residual convolutions
     const int nblk = Cp / 128;
     std::vector<unsigned short> pk(c->conv_layer_elems * 2 * nres, 0);
@@ -284,6 +296,15 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
+    if (c->fused) {
+        const bool on = prof_begin(c, 0, sampled);
+        az_launch_tower_fused(c->stream, planes_dev, c->stem_wbf, c->stem_b, c->conv_w, c->conv_b, c->actX,
+                              B, N, Gd, 2 * c->num_res);
+        prof_end(c, on);
+        az_launch_heads(c->stream, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+        HIPCHK(hipGetLastError());
+        return AZ_OK;
+    }
     az_launch_stem(c->stream, planes_dev, c->actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;

@@ -10,6 +10,9 @@ void az_launch_stem(hipStream_t s, const uint8_t* planes, unsigned short* out, c
 void az_launch_conv3x3(hipStream_t s, const unsigned short* in, unsigned short* out,
                        const unsigned short* resid, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu);
+void az_launch_tower_fused(hipStream_t s, const uint8_t* planes, const unsigned short* stem_w,
+                           const float* stem_b, const unsigned short* wpk, const float* bias,
+                           unsigned short* out, int B, int N, int Gd, int n_layers);
 void az_launch_heads(hipStream_t s, const unsigned short* x, const float* hp, float* policy,
                      float* value, int B, int N, int C_pad, int Gd);
 }

@@ -108,19 +108,15 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 wreg[4];
-    auto load_w = [&](int c) {
-        const uint4* src = (const uint4*)(wbase + (size_t)c * (128 * 64));
-#pragma unroll
-        for (int p = 0; p < 4; ++p) wreg[p] = src[p * 256 + tid];
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int idx = p * 256 + tid;
-            *(uint4*)(sB + buf * B_BUF_BYTES + (idx >> 3) * B_STRIDE + (idx & 7) * 16) = wreg[p];
-        }
-    };
+    // next weight chunk in flight: four named registers (an array captured by a
+    // lambda is demoted to scratch, which exposes the full load latency)
+    uint4 w0, w1, w2, w3;
+    unsigned char* const sBst = sB + (tid >> 3) * B_STRIDE + (tid & 7) * 16;   // idx = p*256 + tid
+#define LOAD_W(c) do { const uint4* src_ = (const uint4*)(wbase + (size_t)(c) * (128 * 64)) + tid; \
+        w0 = src_[0]; w1 = src_[256]; w2 = src_[512]; w3 = src_[768]; } while (0)
+#define STORE_W(buf) do { unsigned char* d_ = sBst + (buf) * B_BUF_BYTES; \
+        *(uint4*)(d_) = w0; *(uint4*)(d_ + 32 * B_STRIDE) = w1; \
+        *(uint4*)(d_ + 64 * B_STRIDE) = w2; *(uint4*)(d_ + 96 * B_STRIDE) = w3; } while (0)
     auto stage_a = [&](int sc) {
         for (int r = tid >> 4; r < a_rows; r += 16) {
             const uint4 v = *(const uint4*)(in + (size_t)(m0 + r) * C_pad + sc * 128 + (tid & 15) * 8);
@@ -129,8 +125,8 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
     };
 
     stage_a(0);
-    load_w(0);
-    store_w(0);
+    LOAD_W(0);
+    STORE_W(0);
     __syncthreads();
 
     const int posrow0 = Gd + 64 * wv + l31;            // LDS row of this lane's position, tile j adds 32
@@ -138,7 +134,7 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
         const int cc = c % 18;
         const int tap = cc >> 1, kc = cc & 1;
         const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
-        if (c + 1 < total) load_w(c + 1);
+        if (c + 1 < total) LOAD_W(c + 1);
         const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + kc * 128 + h * 16;
         const unsigned char* bB = sB + (c & 1) * B_BUF_BYTES + l31 * B_STRIDE + h * 16;
 #pragma unroll
@@ -159,10 +155,12 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
                 __syncthreads();
                 stage_a((c + 1) / 18);
             }
-            store_w((c + 1) & 1);
+            STORE_W((c + 1) & 1);
         }
         __syncthreads();
     }
+#undef LOAD_W
+#undef STORE_W
 
     // epilogue: + bias (+ residual), ReLU, zero the padding raster, bf16 store
 #pragma unroll
@@ -192,6 +190,191 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
                 }
                 *(uint2*)(out + rowoff + cch) = o;
             }
+    }
+}
+
+// ------------------------------------------------------------ fused tower
+// The whole tower for one tile of boards in ONE launch (C <= 128, (N+1)^2 <= 256):
+// a workgroup keeps its boards' activations resident in LDS (bf16, zero-padded
+// raster with zero guard rows), streams only weights (16 KB chunks, L2-resident,
+// shared by every workgroup) and carries the residual stream in fp32 registers
+// in the MFMA C/D layout, so between the stem and the heads no activation byte
+// touches HBM.  A tile holds bpt = 256 / (N+1)^2 whole boards; no halo exchange.
+//   stem  : im2col of the u8 planes (K = 27 -> 32) + 2 MFMA k-steps
+//   block : conv1 -> ReLU -> LDS ; conv2 + fp32 residual -> ReLU -> LDS
+#define I_STRIDE 80             // 32 k * 2 B + 16 B pad
+
+extern "C" __global__ void __launch_bounds__(256)
+az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
+                      const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
+                      const float* __restrict__ bias, unsigned short* __restrict__ out,
+                      int B, int N, int Gd, int n_layers, int bpt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = N + 1, P = W * W, A = N * N;
+    const int a_rows = TILE_M + 2 * Gd;
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
+    unsigned char* sI = sB;                                  // stem im2col [256][I_STRIDE]
+    unsigned char* sW = sB + TILE_M * I_STRIDE;              // stem weights [128][I_STRIDE]
+    uint8_t* sP = sB + 2 * B_BUF_BYTES;                      // planes of this tile's boards
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b0 = blockIdx.x * bpt;                         // first board of the tile
+    const int nb_here = min(bpt, B - b0);
+    const int rows_here = nb_here * P;                       // tile rows that belong to boards
+
+    // zero the activation tile (guards and idle rows stay zero for the whole kernel)
+    for (int i = tid; i < a_rows * (A_STRIDE / 16); i += 256) *(uint4*)(sA + i * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < nb_here * 3 * A; i += 256) sP[i] = planes[(size_t)b0 * 3 * A + i];
+    for (int i = tid; i < 128 * 4; i += 256)
+        *(uint4*)(sW + (i >> 2) * I_STRIDE + (i & 3) * 16) = *(const uint4*)(stem_w + (size_t)i * 8);
+    __syncthreads();
+    {   // im2col row of tile position `tid`: k = ci*9 + ky*3 + kx, bf16(u8) is exact
+        unsigned short v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = 0;
+        const int r = tid;
+        if (r < rows_here) {
+            const int bi = r / P, p = r % P, y = p / W, x = p % W;
+            if (y < N && x < N) {
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yy = y + ky - 1, xx = x + kx - 1;
+                            if (yy >= 0 && yy < N && xx >= 0 && xx < N)
+                                v[ci * 9 + ky * 3 + kx] = f2bf((float)sP[(bi * 3 + ci) * A + yy * N + xx]);
+                        }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 pk;
+            pk.x = v[8 * q + 0] | ((unsigned)v[8 * q + 1] << 16); pk.y = v[8 * q + 2] | ((unsigned)v[8 * q + 3] << 16);
+            pk.z = v[8 * q + 4] | ((unsigned)v[8 * q + 5] << 16); pk.w = v[8 * q + 6] | ((unsigned)v[8 * q + 7] << 16);
+            *(uint4*)(sI + r * I_STRIDE + q * 16) = pk;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[4][2];
+    float res[4][2][16];                                     // fp32 residual stream, C/D layout
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // which of this lane's two positions are real board cells
+    bool real[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 64 * wv + 32 * j + l31;
+        const int p = r % P;
+        real[j] = r < rows_here && (p / W) < N && (p % W) < N;
+    }
+
+    // stem: 2 k-steps of 16 over the im2col tile
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xb[2], wa[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xb[j] = *(const bf16x8*)(sI + (64 * wv + 32 * j + l31) * I_STRIDE + ks * 32 + h * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8*)(sW + (32 * i + l31) * I_STRIDE + ks * 32 + h * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xb[j], acc[i][j], 0, 0, 0);
+    }
+    // epilogue shared by the stem and every conv: mode 0 = stem / conv1 (no skip), 1 = conv2 (+ residual)
+    auto epilogue = [&](const float* bptr, int mode) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned char* rowp = sA + (size_t)(Gd + 64 * wv + 32 * j + l31) * A_STRIDE + 8 * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *(const float4*)(bptr + 32 * i + 8 * q + 4 * h);
+                    float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
+                    float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
+                    if (mode == 1) {
+                        v0 += res[i][j][4 * q + 0]; v1 += res[i][j][4 * q + 1];
+                        v2 += res[i][j][4 * q + 2]; v3 += res[i][j][4 * q + 3];
+                    }
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                    if (!real[j]) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+                    if (mode != 2) {
+                        if (mode == 1 || bptr == stem_b) {
+                            res[i][j][4 * q + 0] = v0; res[i][j][4 * q + 1] = v1;
+                            res[i][j][4 * q + 2] = v2; res[i][j][4 * q + 3] = v3;
+                        }
+                    }
+                    uint2 o;
+                    o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                    o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    *(uint2*)(rowp + (32 * i + 8 * q) * 2) = o;
+                    acc[i][j][4 * q + 0] = 0.f; acc[i][j][4 * q + 1] = 0.f;
+                    acc[i][j][4 * q + 2] = 0.f; acc[i][j][4 * q + 3] = 0.f;
+                }
+        }
+    };
+    __syncthreads();                                         // every wave is done with sI / sW
+    epilogue(stem_b, 0);
+
+    uint4 w0, w1, w2, w3;                                    // next weight chunk in flight
+    unsigned char* const sBst = sB + (tid >> 3) * B_STRIDE + (tid & 7) * 16;
+#define LOAD_W(g_) do { const uint4* src_ = (const uint4*)(wpk + (size_t)(g_) * (128 * 64)) + tid; \
+        w0 = src_[0]; w1 = src_[256]; w2 = src_[512]; w3 = src_[768]; } while (0)
+#define STORE_W(buf) do { unsigned char* d_ = sBst + (buf) * B_BUF_BYTES; \
+        *(uint4*)(d_) = w0; *(uint4*)(d_ + 32 * B_STRIDE) = w1; \
+        *(uint4*)(d_ + 64 * B_STRIDE) = w2; *(uint4*)(d_ + 96 * B_STRIDE) = w3; } while (0)
+    const int total = n_layers * 18;
+    LOAD_W(0);
+    STORE_W(0);
+    __syncthreads();
+
+    const int posrow0 = Gd + 64 * wv + l31;
+    int g = 0;
+    for (int L = 0; L < n_layers; ++L) {
+        for (int cc = 0; cc < 18; ++cc, ++g) {
+            const int tap = cc >> 1, kc = cc & 1;
+            const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
+            if (g + 1 < total) LOAD_W(g + 1);
+            const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + kc * 128 + h * 16;
+            const unsigned char* bB = sB + (g & 1) * B_BUF_BYTES + l31 * B_STRIDE + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 xb[2], wa[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xb[j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE + ks * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8*)(bB + i * 32 * B_STRIDE + ks * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xb[j], acc[i][j], 0, 0, 0);
+            }
+            if (g + 1 < total) STORE_W((g + 1) & 1);
+            __syncthreads();
+        }
+        // all waves have finished reading this layer's input: overwrite it in place
+        epilogue(bias + (size_t)L * 128, L & 1);
+        __syncthreads();
+    }
+    // final activations -> HBM rows for the heads kernel (coalesced 16-byte stores)
+    for (int i = tid; i < rows_here * 16; i += 256) {
+        const int r = i >> 4, cpiece = i & 15;
+        const uint4 v = *(const uint4*)(sA + (size_t)(Gd + r) * A_STRIDE + cpiece * 16);
+        *(uint4*)(out + ((size_t)(Gd + b0 * P + r)) * 128 + cpiece * 8) = v;
     }
 }
 
@@ -281,6 +464,8 @@ extern "C" int az_tower_configure(void) {
     hipError_t e = hipFuncSetAttribute((const void*)az_conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)az_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)az_tower_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return (int)e;
 }
 
@@ -296,6 +481,17 @@ extern "C" void az_launch_conv3x3(hipStream_t s, const unsigned short* in, unsig
     const int tiles = (M + TILE_M - 1) / TILE_M;
     hipLaunchKernelGGL(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
                        in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
+}
+
+extern "C" void az_launch_tower_fused(hipStream_t s, const uint8_t* planes, const unsigned short* stem_w,
+                                      const float* stem_b, const unsigned short* wpk, const float* bias,
+                                      unsigned short* out, int B, int N, int Gd, int n_layers) {
+    const int P = (N + 1) * (N + 1);
+    const int bpt = TILE_M / P;
+    const int tiles = (B + bpt - 1) / bpt;
+    const size_t sm = conv_smem(Gd) + (size_t)bpt * 3 * N * N + 16;
+    hipLaunchKernelGGL(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
+                       out, B, N, Gd, n_layers, bpt);
 }
 
 extern "C" void az_launch_heads(hipStream_t s, const unsigned short* x, const float* hp, float* policy,

@@ -130,7 +130,11 @@ def main():
         A = N * N
         C = Cs[0]
         sims = G * args.steps * world                     # one simulation per game per round
-        conv_flops = 2.0 * 9 * A * C * C * G               # real cells only (algorithmic)
+        conv_flops = 2.0 * 9 * A * C * C * G               # one 3x3 conv over G boards, real cells only
+        kernel = "az_conv3x3_kernel"
+        if eng.tower_is_fused():                           # stem + all 2*num_res convs in one launch
+            conv_flops = conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * G
+            kernel = "az_tower_fused_kernel"
         conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
         line = {
             "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
@@ -140,7 +144,7 @@ def main():
                                    "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
                        "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world},
             "moves_per_s": None,
-            "roofline": {"bound": "mfma", "kernel": "az_conv3x3_kernel", "achieved": conv_tflops,
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": conv_tflops,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
                          "flops_per_launch": conv_flops,

@@ -152,6 +152,9 @@ int az_get_stats(az_ctx*, az_stats*);
  * stream around every 3x3-convolution launch and every tree-round launch of
  * each `every`-th evaluator call; every = 0 switches sampling off. */
 int az_profile_enable(az_ctx*, int every);
+/* 1 when the tower runs as ONE launch per evaluation (az_tower_fused_kernel:
+ * C <= 128 and (N+1)^2 <= 256), 0 when it runs one launch per convolution. */
+int az_tower_is_fused(const az_ctx*);
 int az_profile_read(az_ctx*, double* conv_avg_us, int64_t* conv_launches,
                     double* tree_avg_us, int64_t* tree_launches);
 
