@@ -20,7 +20,7 @@ AZ_MAX_LAYERS = 64
 EXPORTS = [
     "az_last_error", "az_ctx_create", "az_ctx_destroy", "az_sync", "az_stream", "az_weights_size",
     "az_load_weights", "az_load_weights_dev", "az_env_reset", "az_env_step", "az_env_boards",
-    "az_env_legal_mask", "az_env_set", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
+    "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused",
@@ -156,6 +156,15 @@ class Engine:
         cells = np.ascontiguousarray(cells, np.uint8)
         to_move = np.ascontiguousarray(to_move, np.uint8)
         _chk(load().az_env_set(self.h, _ptr(cells), _ptr(to_move)))
+
+    def env_load(self, histories):
+        """histories: list of G move lists (cell indices)."""
+        hist = np.zeros((self.G, self.A), np.int32)
+        hl = np.zeros(self.G, np.int32)
+        for g, h in enumerate(histories):
+            hl[g] = len(h)
+            hist[g, :len(h)] = h
+        _chk(load().az_env_load(self.h, _ptr(hist), _ptr(hl)))
 
     # -- MCTS --------------------------------------------------------------
     def set_noise(self, noise):

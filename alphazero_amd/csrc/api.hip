@@ -3,6 +3,7 @@
 // Host code only; kernels live in tree.hip and tower.hip.
 #include "../../include/az_hip.h"
 #include "az_dev.h"
+#include "az_rules.h"
 #include "az_tower.h"
 #include "az_tree.h"
 
@@ -64,12 +65,12 @@ struct az_ctx {
 static bool prof_begin(az_ctx* c, int kind, bool sampled) {
     if (!sampled || c->prof_used + 2 > c->prof_pool.size()) return false;
     c->prof_spans.push_back({c->prof_used, kind});
-    hipEventRecord(c->prof_pool[c->prof_used], c->stream);
+    (void)hipEventRecord(c->prof_pool[c->prof_used], c->stream);
     return true;
 }
 static void prof_end(az_ctx* c, bool on) {
     if (!on) return;
-    hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream);
+    (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream);
     c->prof_used += 2;
 }
 
@@ -184,10 +185,11 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
 
 extern "C" int az_ctx_destroy(az_ctx* c) {
     if (!c) return AZ_OK;
-    hipSetDevice(c->cfg.device);
-    hipStreamSynchronize(c->stream);
-    for (void* p : c->allocs) hipFree(p);
-    hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
     delete c;
     return AZ_OK;
 }
@@ -396,6 +398,39 @@ extern "C" int az_env_set(az_ctx* c, const uint8_t* cells, const uint8_t* to_mov
     std::vector<uint16_t> hist((size_t)G * A, 0xFFFF);
     HIPCHK(hipMemcpy(c->d.hist, hist.data(), hist.size() * 2, hipMemcpyHostToDevice));
     return az_tree_clear(c);
+}
+
+// Env state of every game from its move history (Env::get_id, mcts.hpp:388):
+// replayed on the host with the same rules, then uploaded with the history so
+// that find() (node.hpp:83-102) can reuse the tree.
+extern "C" int az_env_load(az_ctx* c, const int32_t* hist, const int32_t* hist_len) {
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int G = c->cfg.G, A = c->A, N = c->cfg.N;
+    std::vector<uint8_t> cells((size_t)G * A, 0), tm(G, 0), over(G, 0);
+    std::vector<uint16_t> h16((size_t)G * A, 0);
+    std::vector<int> hl(G, 0);
+    std::vector<float> fr(2 * (size_t)G, 0.f);
+    for (int g = 0; g < G; ++g) {
+        int to_move = 0;
+        if (hist_len[g] < 0 || hist_len[g] > A) return fail(AZ_E_ARG, "game %d: history length %d", g, hist_len[g]);
+        for (int t = 0; t < hist_len[g]; ++t) {
+            float r[2];
+            if (over[g]) return fail(AZ_E_ARG, "game %d: move after the game ended", g);
+            const int d = az_rules_step(N, c->cfg.K, cells.data() + (size_t)g * A, &to_move, hist[(size_t)g * A + t], r);
+            if (d < 0) return fail(AZ_E_ARG, "game %d: illegal move %d at ply %d", g, hist[(size_t)g * A + t], t);
+            over[g] = d == 1; fr[2 * g] = r[0]; fr[2 * g + 1] = r[1];
+            h16[(size_t)g * A + t] = (uint16_t)hist[(size_t)g * A + t];
+        }
+        tm[g] = (uint8_t)to_move; hl[g] = hist_len[g];
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(c->d.cells, cells.data(), cells.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.to_move, tm.data(), G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.game_over, over.data(), G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.hist, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.hist_len, hl.data(), sizeof(int) * G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d.final_reward, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
+    return AZ_OK;
 }
 
 extern "C" int az_set_noise(az_ctx* c, const float* noise) {

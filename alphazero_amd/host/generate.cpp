@@ -1,0 +1,62 @@
+// generate.cpp -- this build's self-play producer, the drop-in for the
+// reference's `./generate <nthreads> <iter_budget> <verbosity>`
+// (generate.cpp:37-123): same argv, same ckpt_location.txt weight hand-off,
+// same PUSH stream on tcp://*:5555 in the trainer's 3-frame format, "press
+// enter" to stop (generate.cpp:19-23).  Instead of one game searched by
+// nthreads CPU threads it advances AZ_GAMES (default 512) games in lockstep on
+// the GPU; <nthreads> is accepted and ignored.
+#include <atomic>
+#include <chrono>
+#include <iostream>
+#include <thread>
+
+#include "../include/az/env.hpp"
+#include "../include/az/replay.hpp"
+#include "../include/az/selfplay.hpp"
+
+static std::atomic<bool> alive{true};
+enum { GEN, TRN };
+using Env = az::Gomoku;
+
+static void run() {
+    std::cin.get();
+    alive = false;
+}
+
+int main(int argc, char const* argv[]) {
+    if (argc != 4)
+        throw std::runtime_error("Invalid arguments. Usage: ./generate <nthreads> <iter_budget> <verbosity>");
+    std::thread thd(&run);
+    const int iter_budget = atoi(argv[2]);
+    const int verbosity = atoi(argv[3]);
+    const char* g = getenv("AZ_GAMES");
+    const char* dev = getenv("AZ_DEVICE");
+    const char* port = getenv("AZ_PORT");
+    const char* max_s = getenv("AZ_SECONDS");
+    const int games = g ? atoi(g) : 512;
+
+    az::SelfPlay<Env> agent(games, iter_budget, 3, 3, dev ? atoi(dev) : 0, std::random_device{}());
+    az::ReplayBuffer<Env> buffer(GEN, "*", port ? port : "5555");
+    agent.load();
+    agent.begin();
+    const auto t0 = std::chrono::steady_clock::now();
+    long long rows = 0;
+    while (alive) {
+        agent.run(iter_budget);                   // about one move per slot
+        rows += agent.drain([&](const az::ByteTensor& board, const az::FloatTensor& policy, const az::FloatTensor& reward) {
+            buffer.temporary_append(board, policy);
+            buffer.send_reward(reward);
+        });
+        agent.load();                             // agent.load() per game start in the reference (generate.cpp:73)
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (verbosity >= 1) {
+            const az_stats s = agent.stats();
+            std::cout << "Game count: " << s.games << " | moves: " << s.moves << " | sims/s: " << (double)s.sims / el
+                      << " | rows sent: " << rows * 8 << std::endl;
+        }
+        if (max_s && el > atof(max_s)) break;
+    }
+    alive = false;
+    thd.detach();
+    return 0;
+}

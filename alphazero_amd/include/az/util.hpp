@@ -1,0 +1,140 @@
+// util.hpp -- the checkpoint pointer protocol of util.h:60-139 for the flat
+// weight blob the HIP tower consumes.  `ckpt_location.txt` (read under
+// flock(LOCK_SH), util.h:63-87) names the newest `<prefix>_<ver>.pt`; the blob
+// is looked up as `<that path>.azw` (written by tools/pt2blob.py from the
+// libtorch archive) or, if the named file itself is a blob, read directly.
+#pragma once
+#include <sys/file.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "tensor.hpp"
+
+namespace az {
+
+struct WeightFile {
+    int N = 0, c_in = 0, c_out = 0;
+    std::vector<int> Cs;
+    std::vector<float> blob;
+};
+
+inline bool read_azw(const std::string& path, WeightFile& w) {
+    std::ifstream f(path, std::ios::binary);
+    char magic[4];
+    if (!f.read(magic, 4) || memcmp(magic, "AZW1", 4) != 0) return false;
+    uint32_t h[4];
+    if (!f.read((char*)h, 16)) return false;
+    w.N = (int)h[0]; w.c_in = (int)h[1]; w.c_out = (int)h[2];
+    w.Cs.resize(h[3]);
+    for (auto& c : w.Cs) { uint32_t x; if (!f.read((char*)&x, 4)) return false; c = (int)x; }
+    uint64_t n;
+    if (!f.read((char*)&n, 8)) return false;
+    w.blob.resize(n);
+    return (bool)f.read((char*)w.blob.data(), (std::streamsize)(n * 4));
+}
+
+inline void write_azw(const std::string& path, const WeightFile& w) {
+    std::ofstream f(path, std::ios::binary);
+    f.write("AZW1", 4);
+    const uint32_t h[4] = {(uint32_t)w.N, (uint32_t)w.c_in, (uint32_t)w.c_out, (uint32_t)w.Cs.size()};
+    f.write((const char*)h, 16);
+    for (int c : w.Cs) { const uint32_t x = (uint32_t)c; f.write((const char*)&x, 4); }
+    const uint64_t n = w.blob.size();
+    f.write((const char*)&n, 8);
+    f.write((const char*)w.blob.data(), (std::streamsize)(n * 4));
+}
+
+// Fresh random weights in blob order (the reference saves a freshly constructed
+// network when the named file is missing, util.h:94-97).
+inline std::vector<float> random_blob(size_t n, uint32_t seed) {
+    std::mt19937 g(seed);
+    std::uniform_real_distribution<float> u(-0.05f, 0.05f);
+    std::vector<float> b(n);
+    for (auto& x : b) x = u(g);
+    return b;
+}
+
+// util.h:60-105.  Returns the path named by ckpt_location.txt; fills `w` when
+// the path differs from `current`.  `fresh` supplies weights if nothing exists.
+template <class MakeFresh>
+inline std::string load_network(WeightFile& w, const std::string& current, bool& changed, MakeFresh fresh) {
+    std::cout << "Loading network." << std::endl;
+    const int fd = open("ckpt_location.txt", O_RDONLY);
+    if (fd >= 0) flock(fd, LOCK_SH);
+    std::ifstream loc("ckpt_location.txt");
+    if (!loc.is_open()) {
+        if (fd >= 0) { flock(fd, LOCK_UN); close(fd); }
+        char* cwd = getcwd(nullptr, 0);
+        std::stringstream ss;
+        ss << "\n* ERROR *\n\"ckpt_location.txt\" must be in the working directory.\n"
+           << "Furthermore, the path that \"ckpt_location.txt\" points to must exist.\n"
+           << "Current working directory: " << (cwd ? cwd : "?") << "\n";
+        free(cwd);
+        throw Error(ss.str());
+    }
+    std::string export_path;
+    std::getline(loc, export_path);
+    loc.close();
+    if (fd >= 0) { flock(fd, LOCK_UN); close(fd); }
+    changed = false;
+    if (export_path == current) {
+        std::cout << "No change in network. Resuming with network " << current << std::endl;
+        return current;
+    }
+    if (read_azw(export_path + ".azw", w) || read_azw(export_path, w)) {
+        std::cout << "Network loaded.\nPath: " << export_path << std::endl;
+    } else if (std::ifstream(export_path).good()) {
+        throw Error("checkpoint " + export_path + " is a libtorch archive: convert it with tools/pt2blob.py first");
+    } else {
+        std::cout << "Model path provided by 'ckpt_location.txt' doesn't exist. Creating a new one." << std::endl;
+        fresh(w);
+        write_azw(export_path + ".azw", w);
+    }
+    changed = true;
+    const auto now = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
+    std::cout << "Current time: " << ctime(&now);
+    return export_path;
+}
+
+// util.h:42-58
+inline std::vector<float> dirichlet(int size, float alpha = 0.05f) {
+    static std::mt19937 rng = std::mt19937(std::random_device{}());
+    std::gamma_distribution<float> dist(alpha);
+    std::vector<float> vec((size_t)size);
+    for (auto& f : vec) f = dist(rng);
+    double sum = 0.;
+    for (float f : vec) sum += f;
+    for (float& f : vec) f = (float)(f / sum);
+    return vec;
+}
+
+// util.h:141-167
+inline std::stringstream visualize_stream(const FloatTensor& policy) {
+    static const std::string alphabet = "ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+    std::stringstream st;
+    const int size = (int)policy.shape[1];
+    st << "   ";
+    for (char c : alphabet.substr(0, (size_t)size)) st << c << ' ';
+    st << '\n';
+    for (int i = 0; i < size; ++i) {
+        st << (i < 10 ? " " : "") << i << ' ';
+        for (int j = 0; j < size; ++j) {
+            const int lvl = (int)(policy.v[(size_t)i * size + j] * 10);
+            if (lvl != 0) st << lvl << ' '; else st << ". ";
+        }
+        st << '\n';
+    }
+    return st;
+}
+
+}  // namespace az

@@ -105,6 +105,10 @@ int az_env_step(az_ctx*, const int32_t* actions, float* reward, uint8_t* done);
 int az_env_boards(az_ctx*, uint8_t* planes /* [G,3,N,N] */);
 int az_env_legal_mask(az_ctx*, uint8_t* mask /* [G,N,N] */);
 int az_env_set(az_ctx*, const uint8_t* cells /* [G,N*N] 0/1/2 */, const uint8_t* to_move /* [G] */);
+/* Env::get_id (mcts.hpp:388): set every game from its move history, hist i32
+ * [G,N*N] (row-major, y*N+x), hist_len i32 [G]; keeps the trees so that find()
+ * (node.hpp:83-102) can reuse them. */
+int az_env_load(az_ctx*, const int32_t* hist, const int32_t* hist_len);
 
 /* PVNetwork::forward (network.hpp:117-123) in eval mode as driven by
  * Evaluator::run (evaluator.hpp:113-117): boards u8 [B,3,N,N] ->

@@ -1,0 +1,91 @@
+"""The reference-named C++ shims (alphazero_amd/include/az/*.hpp) end to end
+on the GPU, and this build's `generate` executable feeding a real libzmq PULL
+socket in the reference trainer's format."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from test_wire import find_libzmq, free_port, ZMQ_PULL, ZMQ_RCVMORE, ZMQ_RCVTIMEO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "alphazero_amd", "host")
+
+
+def test_mcts_pvnetwork_shims_play_a_game():
+    exe = os.path.join(HOST, "shim_check")
+    assert os.path.exists(exe), "build alphazero_amd/host first (__graft_entry__.build())"
+    with tempfile.TemporaryDirectory() as d:
+        out = subprocess.run([exe, "50"], cwd=d, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "shim ok" in out.stdout
+        lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("move ")]
+        assert 5 <= len(lines) <= 9
+        # first move: warm-up + search = 2*50 sims on a fresh root: sum = 100/101 (Q9, Q11)
+        assert abs(float(lines[0][5]) - 100.0 / 101.0) < 1e-6
+        for ln in lines:
+            assert 0.9 < float(ln[5]) < 1.0
+        assert os.path.exists(os.path.join(d, "shim_0.pt.azw"))     # created like util.h:94-97
+        pv = [ln for ln in out.stdout.splitlines() if ln.startswith("pvnet")][0].split()
+        assert abs(float(pv[2]) - 1.0) < 1e-4 and abs(float(pv[4])) < 1e-5
+
+
+@pytest.mark.skipif(find_libzmq() is None, reason="no libzmq for the PULL side")
+def test_generate_executable_streams_rows_to_a_pull_socket():
+    exe = os.path.join(HOST, "generate")
+    assert os.path.exists(exe)
+    z = find_libzmq()
+    z.zmq_ctx_new.restype = C.c_void_p
+    z.zmq_socket.restype = C.c_void_p
+    z.zmq_socket.argtypes = [C.c_void_p, C.c_int]
+    z.zmq_connect.argtypes = [C.c_void_p, C.c_char_p]
+    z.zmq_recv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    z.zmq_getsockopt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    z.zmq_setsockopt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    z.zmq_close.argtypes = [C.c_void_p]
+    port = free_port()
+    N = 15
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "ckpt_location.txt"), "w").write("gen_0.pt")
+        env = dict(os.environ, AZ_GAMES="32", AZ_PORT=str(port), AZ_SECONDS="60")
+        proc = subprocess.Popen([exe, "1", "8", "0"], cwd=d, env=env, stdin=subprocess.PIPE,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        try:
+            ctx = z.zmq_ctx_new()
+            sock = z.zmq_socket(ctx, ZMQ_PULL)
+            tmo = C.c_int(60000)
+            z.zmq_setsockopt(sock, ZMQ_RCVTIMEO, C.byref(tmo), C.sizeof(tmo))
+            assert z.zmq_connect(sock, b"tcp://127.0.0.1:%d" % port) == 0
+            buf = C.create_string_buffer(1 << 16)
+            got = 0
+            for _ in range(64):                       # 8 positions x 8 symmetries
+                sizes, mores = [], []
+                for _f in range(3):
+                    n = z.zmq_recv(sock, buf, 1 << 16, 0)
+                    assert n >= 0, "no rows from generate"
+                    more = C.c_int(0)
+                    sz = C.c_size_t(C.sizeof(more))
+                    z.zmq_getsockopt(sock, ZMQ_RCVMORE, C.byref(more), C.byref(sz))
+                    sizes.append(n)
+                    mores.append(bool(more.value))
+                    if _f == 1:
+                        pol = np.frombuffer(buf.raw[:n], np.float32)
+                        assert 0.5 < pol.sum() <= 1.0 + 1e-5
+                assert sizes == [3 * N * N, 4 * N * N, 8] and mores == [True, True, False]
+                got += 1
+            assert got == 64
+            z.zmq_close(sock)
+        finally:
+            try:
+                proc.stdin.write(b"\n")
+                proc.stdin.close()
+            except Exception:
+                pass
+            try:
+                proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                proc.kill()
