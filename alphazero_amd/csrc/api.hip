@@ -42,6 +42,7 @@ struct az_ctx {
     size_t act_rows = 0;
     float *stem_w = nullptr, *stem_b = nullptr;           // [C_pad][27], [C_pad]
     unsigned short* stem_wbf = nullptr;                   // [128][32] bf16, fused path
+    unsigned short* conv_wf = nullptr;                    // [layer][tap][n=128][k=128] bf16, fused path
     bool fused = false;                                   // whole tower in one launch
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
@@ -169,6 +170,7 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
         AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27)); AZCHK(dalloc(c, &c->stem_b, c->C_pad));
         AZCHK(dalloc(c, &c->stem_wbf, (size_t)128 * 32));
+        AZCHK(dalloc(c, &c->conv_wf, (size_t)2 * c->num_res * 9 * 128 * 128));
         c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED");
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
         AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
@@ -268,6 +270,21 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
         }
     }
     HIPCHK(hipMemcpy(c->conv_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    if (c->fused) {                               // one 32 KB chunk per tap: [layer][tap][n][k]
+        std::vector<unsigned short> pf((size_t)2 * nres * 9 * 128 * 128, 0);
+        for (int L = 0; L < 2 * nres; ++L) {
+            const Conv& cv = (L & 1) ? c2[L / 2] : c1[L / 2];
+            const Bn& bb = (L & 1) ? b2[L / 2] : b1[L / 2];
+            for (int co = 0; co < C; ++co) {
+                const double s = scale(bb, co);
+                for (int ci = 0; ci < C; ++ci)
+                    for (int tap = 0; tap < 9; ++tap)
+                        pf[(((size_t)L * 9 + tap) * 128 + co) * 128 + ci] =
+                            host_f2bf((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
+            }
+        }
+        HIPCHK(hipMemcpy(c->conv_wf, pf.data(), pf.size() * 2, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(c->conv_b, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
     // heads
     std::vector<float> hp((size_t)2 * Cp + 2 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
@@ -300,7 +317,7 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled);
-        az_launch_tower_fused(c->stream, planes_dev, c->stem_wbf, c->stem_b, c->conv_w, c->conv_b, c->actX,
+        az_launch_tower_fused(c->stream, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b, c->actX,
                               B, N, Gd, 2 * c->num_res);
         prof_end(c, on);
         az_launch_heads(c->stream, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);

@@ -203,6 +203,9 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 //   stem  : im2col of the u8 planes (K = 27 -> 32) + 2 MFMA k-steps
 //   block : conv1 -> ReLU -> LDS ; conv2 + fp32 residual -> ReLU -> LDS
 #define I_STRIDE 80             // 32 k * 2 B + 16 B pad
+#define W_BUF_BYTES (128 * 256)  // one tap of weights: 128 rows x 128 k bf16
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) void gl_void;
 
 extern "C" __global__ void __launch_bounds__(256)
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
@@ -216,7 +219,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
     unsigned char* sI = sB;                                  // stem im2col [256][I_STRIDE]
     unsigned char* sW = sB + TILE_M * I_STRIDE;              // stem weights [128][I_STRIDE]
-    uint8_t* sP = sB + 2 * B_BUF_BYTES;                      // planes of this tile's boards
+    uint8_t* sP = sB + 2 * W_BUF_BYTES;                      // planes of this tile's boards
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -329,47 +332,82 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();                                         // every wave is done with sI / sW
     epilogue(stem_b, 0);
 
-    uint4 w0, w1, w2, w3;                                    // next weight chunk in flight
-    unsigned char* const sBst = sB + (tid >> 3) * B_STRIDE + (tid & 7) * 16;
-#define LOAD_W(g_) do { const uint4* src_ = (const uint4*)(wpk + (size_t)(g_) * (128 * 64)) + tid; \
-        w0 = src_[0]; w1 = src_[256]; w2 = src_[512]; w3 = src_[768]; } while (0)
-#define STORE_W(buf) do { unsigned char* d_ = sBst + (buf) * B_BUF_BYTES; \
-        *(uint4*)(d_) = w0; *(uint4*)(d_ + 32 * B_STRIDE) = w1; \
-        *(uint4*)(d_ + 64 * B_STRIDE) = w2; *(uint4*)(d_ + 96 * B_STRIDE) = w3; } while (0)
-    const int total = n_layers * 18;
-    LOAD_W(0);
-    STORE_W(0);
+    // Weight stream: one chunk = one 3x3 tap = [n=128][k=128] bf16 = 32 KB,
+    // copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no
+    // staging registers), two buffers.  The LDS image is lane-linear, so the
+    // bank-conflict fix is an XOR swizzle applied to the SOURCE address and again
+    // on the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
+    const int total = n_layers * 9;
+    // piece p (0..7) of chunk g: 256 lanes x 16 B; lane's piece index q = p*256 + tid
+    // -> LDS row q>>4 = p*16 + (tid>>4), physical piece tid&15, logical piece ^ (row&15)
+    const int st_row = tid >> 4;
+    const int st_src = st_row * 128 + (((tid & 15) ^ (st_row & 15)) << 3);       // elements; row&15 == st_row
+    unsigned char* const st_dst = sB + (tid & ~63) * 16;                        // wave-uniform
+#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_global_load_lds( \
+        (gl_void*)(wpk + (size_t)(g_) * (128 * 128) + (p_) * (16 * 128) + st_src), \
+        (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, 0, 0)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) STAGE_W(0, 0, p);
     __syncthreads();
 
     const int posrow0 = Gd + 64 * wv + l31;
+    const int swz = l31 & 15;
     int g = 0;
     for (int L = 0; L < n_layers; ++L) {
-        for (int cc = 0; cc < 18; ++cc, ++g) {
-            const int tap = cc >> 1, kc = cc & 1;
+        for (int tap = 0; tap < 9; ++tap, ++g) {
             const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
-            if (g + 1 < total) LOAD_W(g + 1);
-            const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + kc * 128 + h * 16;
-            const unsigned char* bB = sB + (g & 1) * B_BUF_BYTES + l31 * B_STRIDE + h * 16;
+            const bool more = g + 1 < total;
+            const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + h * 16;
+            const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
+            // fragments double-buffered in registers: the reads of k-step ks+1 are
+            // issued ahead of the MFMAs of k-step ks (one wave per SIMD, so nothing
+            // else hides the LDS latency)
+            bf16x8 fx[2][2], fw[2][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 xb[2], wa[4];
+            for (int j = 0; j < 2; ++j) fx[0][j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xb[j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE + ks * 32);
+            for (int i = 0; i < 4; ++i) fw[0][i] = *(const bf16x8*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8*)(bB + i * 32 * B_STRIDE + ks * 32);
+            for (int ks = 0; ks < 8; ++ks) {
+                // two 4 KB pieces of the next tap in each of the first four k-steps: the DMA
+                // issue cost hides under MFMAs and the last piece still has four k-steps
+                // (~1000 cycles) to land before the barrier
+                if (more && ks < 4) { STAGE_W(g + 1, (g + 1) & 1, 2 * ks); STAGE_W(g + 1, (g + 1) & 1, 2 * ks + 1); }
+                if (ks < 7) {
+                    const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const bf16x8*)(bB + i * 32 * 256 + wo);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][i], fx[ks & 1][j], acc[i][j], 0, 0, 0);
+                if (ks < 7) {
+                    // the six fragment reads of k-step ks+1 go out in the first three MFMA
+                    // gaps, leaving five MFMAs (160 cycles) to cover the LDS latency
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // 2 DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // a DMA piece
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // a DMA piece
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);       // 3 MFMAs
+                }
             }
-            if (g + 1 < total) STORE_W((g + 1) & 1);
-            __syncthreads();
+            __syncthreads();                                 // next tap landed (vmcnt(0)), this one fully read
         }
         // all waves have finished reading this layer's input: overwrite it in place
         epilogue(bias + (size_t)L * 128, L & 1);
         __syncthreads();
     }
+#undef STAGE_W
     // final activations -> HBM rows for the heads kernel (coalesced 16-byte stores)
     for (int i = tid; i < rows_here * 16; i += 256) {
         const int r = i >> 4, cpiece = i & 15;
@@ -489,7 +527,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, const uint8_t* planes, cons
     const int P = (N + 1) * (N + 1);
     const int bpt = TILE_M / P;
     const int tiles = (B + bpt - 1) / bpt;
-    const size_t sm = conv_smem(Gd) + (size_t)bpt * 3 * N * N + 16;
+    const size_t sm = (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)bpt * 3 * N * N + 16;
     hipLaunchKernelGGL(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
                        out, B, N, Gd, n_layers, bpt);
 }
