@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libazhip.so")
 
 AZ_EVAL_TOWER, AZ_EVAL_HASH, AZ_EVAL_EXTERNAL = 0, 1, 2
 AZ_NOISE_EXPLICIT, AZ_NOISE_DEVICE = 0, 1
-AZ_PREC_BF16, AZ_PREC_BF16X3 = 0, 1
+AZ_PREC_BF16, AZ_PREC_FP16 = 0, 1
 AZ_MAX_LAYERS = 64
 
 EXPORTS = [

@@ -44,6 +44,7 @@ struct az_ctx {
     unsigned short* stem_wbf = nullptr;                   // [128][32] bf16, fused path
     unsigned short* conv_wf = nullptr;                    // [layer][tap][n=128][k=128] bf16, fused path
     bool fused = false;                                   // whole tower in one launch
+    int prec = 0;                                         // 0 bf16, 1 fp16 operands
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
     float* head_p = nullptr;
@@ -106,7 +107,8 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         for (int i = 1; i < cfg->n_Cs; ++i)
             if (cfg->Cs[i] != cfg->Cs[0])
                 return fail(AZ_E_ARG, "ResBlock widths must be uniform (x + input, network.hpp:36)");
-        if (cfg->precision != AZ_PREC_BF16) return fail(AZ_E_ARG, "precision %d not available in this build", cfg->precision);
+        if (cfg->precision != AZ_PREC_BF16 && cfg->precision != AZ_PREC_FP16)
+            return fail(AZ_E_ARG, "precision %d unknown (AZ_PREC_BF16, AZ_PREC_FP16)", cfg->precision);
     }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -164,6 +166,7 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         c->C = cfg->Cs[0];
         c->C_pad = (c->C + 127) / 128 * 128;
         c->num_res = cfg->n_Cs - 1;
+        c->prec = cfg->precision == AZ_PREC_FP16 ? 1 : 0;
         const size_t M_pad = ((size_t)c->Bmax * c->P + 255) / 256 * 256;
         c->act_rows = M_pad + 2 * (size_t)c->Gd;
         AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
@@ -211,6 +214,29 @@ static inline unsigned short host_f2bf(float x) {
     return (unsigned short)(u >> 16);
 }
 
+// fp32 -> fp16 bits, round to nearest even, saturating at +-65504
+static inline unsigned short host_f2h(float x) {
+    if (x > 65504.f) x = 65504.f;
+    if (x < -65504.f) x = -65504.f;
+    unsigned u; memcpy(&u, &x, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xFF) - 127 + 15;
+    unsigned m = u & 0x7FFFFFu;
+    if (e <= 0) {                                   // subnormal or zero
+        if (e < -10) return (unsigned short)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        unsigned hm = m >> shift;
+        const unsigned rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) ++hm;
+        return (unsigned short)(sign | hm);
+    }
+    unsigned h = ((unsigned)e << 10) | (m >> 13);
+    const unsigned rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (unsigned short)(sign | h);
+}
+
 // BatchNorm (eval, eps 1e-5: network.hpp:13,29-30,71) folded into the preceding
 // convolution in double; 3x3 kernels re-laid as [nb][sc][tap][kc][n][k] chunks.
 extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
@@ -218,6 +244,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     if (n_floats != az_weights_size(c)) return fail(AZ_E_ARG, "blob has %zu floats, expected %zu", n_floats, az_weights_size(c));
     HIPCHK(hipSetDevice(c->cfg.device));
     const int N = c->cfg.N, A = N * N, C = c->C, Cp = c->C_pad, nres = c->num_res;
+    auto to16 = [c](float x) { return c->prec == 1 ? host_f2h(x) : host_f2bf(x); };
     const float* p = blob;
     struct Conv { const float *w, *b; };
     struct Bn { const float *g, *b, *rm, *rv; };
@@ -244,7 +271,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     if (c->fused) {
         std::vector<unsigned short> swb((size_t)128 * 32, 0);
         for (int co = 0; co < C; ++co)
-            for (int k = 0; k < 27; ++k) swb[(size_t)co * 32 + k] = host_f2bf(sw[(size_t)co * 27 + k]);
+            for (int k = 0; k < 27; ++k) swb[(size_t)co * 32 + k] = to16(sw[(size_t)co * 27 + k]);
         HIPCHK(hipMemcpy(c->stem_wbf, swb.data(), swb.size() * 2, hipMemcpyHostToDevice));
     }
     // residual convolutions
@@ -264,7 +291,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
                 for (int tap = 0; tap < 9; ++tap) {
                     const size_t chunk = (((size_t)nb * nblk + sc) * 9 + tap) * 2 + kc;
                     dst[chunk * (128 * 64) + (size_t)n * 64 + k] =
-                        host_f2bf((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
+                        to16((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
                 }
             }
         }
@@ -280,7 +307,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
                 for (int ci = 0; ci < C; ++ci)
                     for (int tap = 0; tap < 9; ++tap)
                         pf[(((size_t)L * 9 + tap) * 128 + co) * 128 + ci] =
-                            host_f2bf((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
+                            to16((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
             }
         }
         HIPCHK(hipMemcpy(c->conv_wf, pf.data(), pf.size() * 2, hipMemcpyHostToDevice));
@@ -317,25 +344,25 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled);
-        az_launch_tower_fused(c->stream, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b, c->actX,
+        az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b, c->actX,
                               B, N, Gd, 2 * c->num_res);
         prof_end(c, on);
-        az_launch_heads(c->stream, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+        az_launch_heads(c->stream, c->prec, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
-    az_launch_stem(c->stream, planes_dev, c->actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
+    az_launch_stem(c->stream, c->prec, planes_dev, c->actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
         bool on = prof_begin(c, 0, sampled);
-        az_launch_conv3x3(c->stream, c->actX, c->actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->actX, c->actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on);
         on = prof_begin(c, 0, sampled);
-        az_launch_conv3x3(c->stream, c->actH, c->actX, c->actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->actH, c->actX, c->actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on);
     }
-    az_launch_heads(c->stream, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+    az_launch_heads(c->stream, c->prec, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }

@@ -1,18 +1,18 @@
-// Host-side launchers of the tower kernels (tower.hip).
+// Host-side launchers of the tower kernels (tower.hip).  prec: 0 bf16, 1 fp16 operands.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 extern "C" {
 int  az_tower_configure(void);
-void az_launch_stem(hipStream_t s, const uint8_t* planes, unsigned short* out, const float* w,
+void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, const float* w,
                     const float* bias, int B, int N, int C_pad, int Gd);
-void az_launch_conv3x3(hipStream_t s, const unsigned short* in, unsigned short* out,
+void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
                        const unsigned short* resid, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu);
-void az_launch_tower_fused(hipStream_t s, const uint8_t* planes, const unsigned short* stem_w,
+void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                            const float* stem_b, const unsigned short* wpk, const float* bias,
                            unsigned short* out, int B, int N, int Gd, int n_layers);
-void az_launch_heads(hipStream_t s, const unsigned short* x, const float* hp, float* policy,
+void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,
                      float* value, int B, int N, int C_pad, int Gd);
 }

@@ -24,16 +24,41 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define B_STRIDE 144            // 64 k * 2 B + 16 B pad
 #define B_BUF_BYTES (128 * B_STRIDE)
 
-__device__ __forceinline__ unsigned short f2bf(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// 16-bit operand formats of the MFMA path.  PR = 0: bf16 (8-bit significand,
+// fp32 range); PR = 1: fp16 (11-bit significand, saturated at +-65504).  Both
+// accumulate in fp32 and run at the same MFMA rate.
+template <int PR> struct Prec;
+template <> struct Prec<0> {
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ unsigned short to16(float x) {
+        unsigned u = __float_as_uint(x);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+    static __device__ __forceinline__ float from16(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+    static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Prec<1> {
+    typedef f16x8 vec;
+    static __device__ __forceinline__ unsigned short to16(float x) {
+        x = fminf(fmaxf(x, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)x;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ float from16(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+    static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 
 // ------------------------------------------------------------------- stem
 // One block per board.  w: [C_pad][27] fp32 (BN folded), bias [C_pad].
-extern "C" __global__ void __launch_bounds__(256)
+template <int PR>
+__global__ void __launch_bounds__(256)
 az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out,
                const float* __restrict__ w, const float* __restrict__ bias,
                int N, int C_pad, int Gd) {
@@ -68,7 +93,7 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
                 }
             a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f);
         }
-        const unsigned pk = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+        const unsigned pk = (unsigned)Prec<PR>::to16(a0) | ((unsigned)Prec<PR>::to16(a1) << 16);
         *(unsigned*)(out + ((size_t)(Gd + b * P + p)) * C_pad + c) = pk;
     }
 }
@@ -81,7 +106,8 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
 // (bf16, BN scale folded), streamed through a double-buffered LDS stage;
 // the activation tile with its halo is staged once per 128-channel slab and
 // reused by all 9 taps.
-extern "C" __global__ void __launch_bounds__(256)
+template <int PR>
+__global__ void __launch_bounds__(256)
 az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
                   const unsigned short* __restrict__ resid, const unsigned short* __restrict__ wpk,
                   const float* __restrict__ bias, int C_pad, int M, int N, int Gd, int relu) {
@@ -139,16 +165,16 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
         const unsigned char* bB = sB + (c & 1) * B_BUF_BYTES + l31 * B_STRIDE + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 xb[2], wa[4];
+            typename Prec<PR>::vec xb[2], wa[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xb[j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE + ks * 32);
+            for (int j = 0; j < 2; ++j) xb[j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + ks * 32);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8*)(bB + i * 32 * B_STRIDE + ks * 32);
+            for (int i = 0; i < 4; ++i) wa[i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * B_STRIDE + ks * 32);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = Prec<PR>::mfma(wa[i], xb[j], acc[i][j]);
         }
         if (c + 1 < total) {
             if ((c + 1) % 18 == 0) {                   // next 128-channel slab of the input
@@ -179,14 +205,14 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
                 float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
                 if (resid) {
                     const uint2 rv = *(const uint2*)(resid + rowoff + cch);
-                    v0 += bf2f((unsigned short)(rv.x & 0xFFFFu)); v1 += bf2f((unsigned short)(rv.x >> 16));
-                    v2 += bf2f((unsigned short)(rv.y & 0xFFFFu)); v3 += bf2f((unsigned short)(rv.y >> 16));
+                    v0 += Prec<PR>::from16((unsigned short)(rv.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(rv.x >> 16));
+                    v2 += Prec<PR>::from16((unsigned short)(rv.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(rv.y >> 16));
                 }
                 if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 uint2 o = make_uint2(0u, 0u);
                 if (real) {
-                    o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                    o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
+                    o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                 }
                 *(uint2*)(out + rowoff + cch) = o;
             }
@@ -207,7 +233,8 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) void gl_void;
 
-extern "C" __global__ void __launch_bounds__(256)
+template <int PR>
+__global__ void __launch_bounds__(256)
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
                       const float* __restrict__ bias, unsigned short* __restrict__ out,
@@ -250,7 +277,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                         for (int kx = 0; kx < 3; ++kx) {
                             const int yy = y + ky - 1, xx = x + kx - 1;
                             if (yy >= 0 && yy < N && xx >= 0 && xx < N)
-                                v[ci * 9 + ky * 3 + kx] = f2bf((float)sP[(bi * 3 + ci) * A + yy * N + xx]);
+                                v[ci * 9 + ky * 3 + kx] = Prec<PR>::to16((float)sP[(bi * 3 + ci) * A + yy * N + xx]);
                         }
             }
         }
@@ -285,16 +312,16 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     // stem: 2 k-steps of 16 over the im2col tile
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 xb[2], wa[4];
+        typename Prec<PR>::vec xb[2], wa[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xb[j] = *(const bf16x8*)(sI + (64 * wv + 32 * j + l31) * I_STRIDE + ks * 32 + h * 16);
+        for (int j = 0; j < 2; ++j) xb[j] = *(const typename Prec<PR>::vec*)(sI + (64 * wv + 32 * j + l31) * I_STRIDE + ks * 32 + h * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8*)(sW + (32 * i + l31) * I_STRIDE + ks * 32 + h * 16);
+        for (int i = 0; i < 4; ++i) wa[i] = *(const typename Prec<PR>::vec*)(sW + (32 * i + l31) * I_STRIDE + ks * 32 + h * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = Prec<PR>::mfma(wa[i], xb[j], acc[i][j]);
     }
     // epilogue shared by the stem and every conv: mode 0 = stem / conv1 (no skip), 1 = conv2 (+ residual)
     auto epilogue = [&](const float* bptr, int mode) {
@@ -321,8 +348,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                         }
                     }
                     uint2 o;
-                    o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                    o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
+                    o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                     *(uint2*)(rowp + (32 * i + 8 * q) * 2) = o;
                     acc[i][j][4 * q + 0] = 0.f; acc[i][j][4 * q + 1] = 0.f;
                     acc[i][j][4 * q + 2] = 0.f; acc[i][j][4 * q + 3] = 0.f;
@@ -362,11 +389,11 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             // fragments double-buffered in registers: the reads of k-step ks+1 are
             // issued ahead of the MFMAs of k-step ks (one wave per SIMD, so nothing
             // else hides the LDS latency)
-            bf16x8 fx[2][2], fw[2][4];
+            typename Prec<PR>::vec fx[2][2], fw[2][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fx[0][j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE);
+            for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fw[0][i] = *(const bf16x8*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
+            for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 // two 4 KB pieces of the next tap in each of the first four k-steps: the DMA
@@ -376,15 +403,15 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                 if (ks < 7) {
                     const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const bf16x8*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
+                    for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const bf16x8*)(bB + i * 32 * 256 + wo);
+                    for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + wo);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][i], fx[ks & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = Prec<PR>::mfma(fw[ks & 1][i], fx[ks & 1][j], acc[i][j]);
                 if (ks < 7) {
                     // the six fragment reads of k-step ks+1 go out in the first three MFMA
                     // gaps, leaving five MFMAs (160 cycles) to cover the LDS latency
@@ -421,7 +448,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 // ValueHead: 1x1 conv -> BN(1) -> ReLU -> fc1 (N*N -> 64) -> ReLU -> fc2 -> softmax*2-1.
 // hp layout (fp32): wp[C_pad], wv[C_pad], {bp, bv (BN folded into wv/bv)}, then
 // fc1w [64][A], fc1b [64], fc2w [2][64], fc2b [2].
-extern "C" __global__ void __launch_bounds__(256)
+template <int PR>
+__global__ void __launch_bounds__(256)
 az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ hp,
                 float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -448,7 +476,7 @@ az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ 
             const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float lo = bf2f((unsigned short)(u[t] & 0xFFFFu)), hi = bf2f((unsigned short)(u[t] >> 16));
+                const float lo = Prec<PR>::from16((unsigned short)(u[t] & 0xFFFFu)), hi = Prec<PR>::from16((unsigned short)(u[t] >> 16));
                 sp += lo * wp[c + 2 * t] + hi * wp[c + 2 * t + 1];
                 sv += lo * wvv[c + 2 * t] + hi * wvv[c + 2 * t + 1];
             }
@@ -499,41 +527,45 @@ az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ 
 static inline size_t conv_smem(int Gd) { return (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * B_BUF_BYTES; }
 
 extern "C" int az_tower_configure(void) {
-    hipError_t e = hipFuncSetAttribute((const void*)az_conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)az_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)az_tower_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipSuccess;
+#define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
+    SETA(az_conv3x3_kernel<0>, 160 * 1024); SETA(az_conv3x3_kernel<1>, 160 * 1024);
+    SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
+    SETA(az_tower_fused_kernel<0>, 160 * 1024); SETA(az_tower_fused_kernel<1>, 160 * 1024);
+#undef SETA
     return (int)e;
 }
 
-extern "C" void az_launch_stem(hipStream_t s, const uint8_t* planes, unsigned short* out, const float* w,
+// prec: 0 = bf16 operands, 1 = fp16 operands
+#define BY_PREC(kern, ...) do { if (prec == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
+
+extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, const float* w,
                                const float* bias, int B, int N, int C_pad, int Gd) {
     const size_t sm = (size_t)C_pad * 28 * 4 + 3 * N * N + 16;
-    hipLaunchKernelGGL(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, w, bias, N, C_pad, Gd);
+    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, w, bias, N, C_pad, Gd);
 }
 
-extern "C" void az_launch_conv3x3(hipStream_t s, const unsigned short* in, unsigned short* out,
+extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
                                   const unsigned short* resid, const unsigned short* wpk, const float* bias,
                                   int C_pad, int M, int N, int Gd, int relu) {
     const int tiles = (M + TILE_M - 1) / TILE_M;
-    hipLaunchKernelGGL(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
-                       in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
+    BY_PREC(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
+            in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
 }
 
-extern "C" void az_launch_tower_fused(hipStream_t s, const uint8_t* planes, const unsigned short* stem_w,
+extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                                       const float* stem_b, const unsigned short* wpk, const float* bias,
                                       unsigned short* out, int B, int N, int Gd, int n_layers) {
     const int P = (N + 1) * (N + 1);
     const int bpt = TILE_M / P;
     const int tiles = (B + bpt - 1) / bpt;
     const size_t sm = (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)bpt * 3 * N * N + 16;
-    hipLaunchKernelGGL(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
-                       out, B, N, Gd, n_layers, bpt);
+    BY_PREC(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
+            out, B, N, Gd, n_layers, bpt);
 }
 
-extern "C" void az_launch_heads(hipStream_t s, const unsigned short* x, const float* hp, float* policy,
+extern "C" void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,
                                 float* value, int B, int N, int C_pad, int Gd) {
     const size_t sm = (size_t)(2 * N * N + 256 + 64) * 4;
-    hipLaunchKernelGGL(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd);
+    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd);
 }

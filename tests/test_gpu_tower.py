@@ -37,33 +37,35 @@ def torch_reference(N, Cs, blob, boards):
     return p.numpy(), v.numpy()
 
 
+@pytest.mark.parametrize("prec", [capi.AZ_PREC_BF16, capi.AZ_PREC_FP16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("path", TOWER_FIX, ids=[os.path.basename(p) for p in TOWER_FIX])
-def test_tower_matches_reference_fixture(path):
+def test_tower_matches_reference_fixture(path, prec):
     z = np.load(path)
     N, Cs, B = int(z["N"]), [int(c) for c in z["Cs"]], int(z["B"])
     blob = synth.make_blob(N, 3, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]))
-    eng = capi.Engine(N, min(N, 5), B, Cs=Cs)
+    eng = capi.Engine(N, min(N, 5), B, Cs=Cs, precision=prec)
     eng.load_weights(blob)
     pol, val = eng.tower_forward(z["boards"])
     perr, verr = np.abs(pol - z["policy"]).max(), np.abs(val - z["value"]).max()
-    print(os.path.basename(path), "policy err %.3g value err %.3g" % (perr, verr))
-    if float(z["phead_gain"]) > 1.0:
-        # heads sharpened 20x: plain bf16 operands exceed 1e-3 here by design;
-        # recorded so the limit of AZ_PREC_BF16 stays visible
-        assert perr < 5e-2 and verr < 5e-2
+    print(os.path.basename(path), "prec", prec, "policy err %.3g value err %.3g" % (perr, verr))
+    if float(z["phead_gain"]) > 1.0 and prec == capi.AZ_PREC_BF16:
+        # heads sharpened 5-20x (a trained-network-like peaked policy): bf16 operands
+        # (8-bit significand) exceed 1e-3 there; AZ_PREC_FP16 is the mode that holds it
+        assert perr < 2e-2 and verr < 2e-2
     else:
         assert perr < TOL and verr < TOL
 
 
-@pytest.mark.parametrize("N,B", [(9, 37), (15, 64), (15, 3), (19, 5)])
-def test_tower_matches_torch_fp32(N, B):
+@pytest.mark.parametrize("prec", [capi.AZ_PREC_BF16, capi.AZ_PREC_FP16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("N,B", [(9, 37), (15, 64), (15, 3), (19, 5), (3, 40)])
+def test_tower_matches_torch_fp32(N, B, prec):
     """Ragged batch sizes (tiles that straddle boards, partial last tile)."""
     import torch
     torch.set_num_threads(8)
     Cs = synth.NETCONFIG2
     blob = synth.make_blob(N, 3, Cs, 11 + N)
     boards = synth.random_boards(B, N, seed=N)
-    eng = capi.Engine(N, 5, max(B, 4), Cs=Cs)
+    eng = capi.Engine(N, min(N, 5), max(B, 4), Cs=Cs, precision=prec)
     eng.load_weights(blob)
     pol, val = eng.tower_forward(boards)
     with torch.no_grad():
@@ -73,6 +75,40 @@ def test_tower_matches_torch_fp32(N, B):
     # a second, smaller call must not see stale rows of the first
     pol2, val2 = eng.tower_forward(boards[:2])
     assert np.abs(pol2 - rp[:2]).max() < TOL and np.abs(val2 - rv[:2]).max() < TOL
+
+
+def test_per_layer_path_matches_fused_path(monkeypatch):
+    """The per-convolution kernels (used for C > 128 or N > 15) against the
+    fused kernel on a shape both can run."""
+    N, B, Cs = 15, 9, synth.NETCONFIG2
+    blob = synth.make_blob(N, 3, Cs, 21)
+    boards = synth.random_boards(B, N, seed=21)
+    e1 = capi.Engine(N, 5, B, Cs=Cs)
+    assert e1.tower_is_fused()
+    e1.load_weights(blob)
+    p1, v1 = e1.tower_forward(boards)
+    monkeypatch.setenv("AZ_NO_FUSED", "1")
+    e2 = capi.Engine(N, 5, B, Cs=Cs)
+    assert not e2.tower_is_fused()
+    e2.load_weights(blob)
+    p2, v2 = e2.tower_forward(boards)
+    assert np.abs(p1 - p2).max() < TOL and np.abs(v1 - v2).max() < TOL
+
+
+def test_wide_tower_256_channels_matches_torch():
+    """BASELINE config 5 shape class: 256-channel blocks (per-layer path)."""
+    import torch
+    torch.set_num_threads(8)
+    N, B, Cs = 9, 6, [256, 256, 256]
+    blob = synth.make_blob(N, 3, Cs, 31)
+    boards = synth.random_boards(B, N, seed=31)
+    eng = capi.Engine(N, 5, B, Cs=Cs)
+    assert not eng.tower_is_fused()
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(boards)
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, boards)
+    assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
 
 
 def test_tower_requires_weights_and_uniform_widths():
