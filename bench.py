@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--budget", type=int, default=800)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--full-games", type=float, default=0.0,
+                    help="after the timed region keep playing for this many seconds and report finished games/hour")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,8 +91,9 @@ def main():
 
     N, K, G, budget = args.board, 5, args.games, args.budget
     Cs = synth.NETCONFIG2
+    prec = capi.AZ_PREC_FP16 if args.precision == "fp16" else capi.AZ_PREC_BF16
     eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
-                      device=local_rank, game_slot_base=rank * G)
+                      device=local_rank, game_slot_base=rank * G, precision=prec)
     # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
     nw = eng.weights_size()
     if world > 1:
@@ -125,6 +129,22 @@ def main():
     st = eng.stats()
     if st["error_games"]:
         raise SystemExit("tree arena overflow in %d games" % st["error_games"])
+    games_info = None
+    if args.full_games > 0:
+        # whole games: keep the same engine running, count games finished per wall second
+        eng.profile_enable(0)
+        t1 = time.perf_counter()
+        g0, m0 = st["games"], st["moves"]
+        while time.perf_counter() - t1 < args.full_games:
+            eng.selfplay_run(budget)
+            eng.replay_drain(1 << 15)
+            eng.sync()
+        el2 = time.perf_counter() - t1
+        st2 = eng.stats()
+        games_info = {"seconds": el2, "games": st2["games"] - g0, "moves": st2["moves"] - m0,
+                      "games_per_hour": (st2["games"] - g0) / el2 * 3600.0,
+                      "mean_game_length": (st2["moves"] - m0) / max(1, st2["games"] - g0),
+                      "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"]}
 
     if rank == 0:
         A = N * N
@@ -139,18 +159,18 @@ def main():
         line = {
             "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
                                    "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
                        "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world},
-            "moves_per_s": None,
+            "moves_per_s": sims / el / budget,
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": conv_tflops,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
                          "flops_per_launch": conv_flops,
                          "tree_round_avg_us": prof["tree_avg_us"]},
         }
-        line["games_per_hour_est"] = None
+        line["full_games"] = games_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, N, K, budget, 16)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,118 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through
+size-independent properties plus bit-exact spot checks against the oracle."""
+import numpy as np
+import pytest
+
+import azo
+from alphazero_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def tree_invariants(eng, g, root_n):
+    """Visit bookkeeping of a settled tree (no virtual loss pending):
+    every expanded node's incoming visits = 1 + visits of its children, and the
+    root's n - 1 = visits of its children (mcts.hpp:337-345)."""
+    d = eng.tree_dump(g)
+    into = {0: root_n}
+    for e in range(len(d["n"])):
+        if d["child"][e] >= 0:
+            into[int(d["child"][e])] = int(d["n"][e])
+    for node in range(len(d["node_first"])):
+        fe, ne = int(d["node_first"][node]), int(d["node_count"][node])
+        assert into[node] == 1 + int(d["n"][fe:fe + ne].sum()), (g, node)
+        acts = d["action"][fe:fe + ne]
+        assert (np.diff(acts) > 0).all()                       # children in row-major order
+    n, v = d["n"].astype(np.float64), d["v"].astype(np.float64)
+    assert (d["n"] >= 0).all()
+    vis = d["n"] > 0
+    assert (np.abs(v[vis] / n[vis]) <= 1.0 + 1e-6).all()       # |q| <= 1
+    assert (d["v"][~vis] == 0).all()
+
+
+def test_config1_gomoku9_256games_400sims_hash_evaluator():
+    """configs[1]: gomoku 9x9, 256 concurrent games x 400 sims/move, one GPU."""
+    N, K, G, budget = 9, 5, 256, 400
+    A = N * N
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget)
+    noise = np.stack([azo.dirichlet(1000 + g, A)[0] for g in range(G)])
+    eng.set_noise(noise)
+    eng.env_reset()
+    hist = [[] for _ in range(G)]
+    orc = {g: azo.MCTS(N, K, 3.0, 3.0, "hash") for g in (0, 1, 100, 255)}
+    for mv in range(3):
+        out = eng.search(budget)
+        _, rn = eng.search_result() if False else (None, None)
+        for g in orc:
+            ref = orc[g].search(hist[g], budget, noise[g])
+            assert np.array_equal(out[g], ref)
+            assert eng.tree_canonical(g) == azo.canonical_tree(orc[g].dump())
+        # all games: policy = n_child / n_root sums to (n_root - 1) / n_root, support on empty cells
+        boards = eng.env_boards()
+        occupied = (boards[:, 0] + boards[:, 1]).reshape(G, A) > 0
+        assert (out[occupied] == 0).all()
+        for g in (3, 77, 200):
+            d = eng.tree_dump(g)
+            root_n = 1 + int(d["n"][:d["node_count"][0]].sum())
+            tree_invariants(eng, g, root_n)
+            assert abs(out[g].sum() - (root_n - 1) / root_n) < 1e-5
+        acts = out.argmax(1).astype(np.int32)
+        _, done = eng.env_step(acts)
+        for g in range(G):
+            hist[g].append(int(acts[g]))
+        assert not done.any()
+
+
+def test_config2_gomoku15_512games_800sims_tower():
+    """configs[2] per-GPU shard: gomoku 15x15, 512 games x 800 sims/move, NetConfig-2 tower."""
+    N, K, G, budget = 15, 5, 512, 800
+    A = N * N
+    Cs = synth.NETCONFIG2
+    eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=5)
+    eng.load_weights(synth.make_blob(N, 3, Cs, 0, phead_gain=8.0, fc2_gain=4.0))
+    eng.env_reset()
+    out = eng.search(budget)
+    assert np.isfinite(out).all()
+    # fresh roots: n = 1 + 800 (mcts.hpp:413, Q10) => policy sums to 800/801 for every game
+    assert np.allclose(out.sum(1), 800.0 / 801.0, atol=2e-5)
+    for g in (0, 17, 511):
+        tree_invariants(eng, g, 801)
+    # second search after a move: roots are reused (n grows by exactly 800)
+    acts = out.argmax(1).astype(np.int32)
+    n_child = np.rint(out.max(1) * 801).astype(int)
+    eng.env_step(acts)
+    out2 = eng.search(budget)
+    for g in (0, 17, 511):
+        tree_invariants(eng, g, int(n_child[g]) + 800)
+        assert abs(out2[g].sum() - (n_child[g] + 799) / (n_child[g] + 800)) < 2e-5
+        assert out2[g][acts[g]] == 0
+    st = eng.stats()
+    assert st["error_games"] == 0
+
+
+def test_selfplay_rows_are_consistent_full_size():
+    """Device-side generate loop at 15x15 / 512 games with the tower: every
+    emitted row is a legal position of an alternating-move game, its policy
+    lives on empty cells and sums to (n-1)/n, rewards are one of the three outcomes."""
+    N, K, G, budget = 15, 5, 512, 32
+    A = N * N
+    Cs = synth.NETCONFIG2
+    eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=9)
+    eng.load_weights(synth.make_blob(N, 3, Cs, 1, phead_gain=8.0))
+    eng.selfplay_begin(budget)
+    eng.selfplay_run(budget * 120)
+    cells, tm, pol, rew = eng.replay_drain(1 << 16)
+    st = eng.stats()
+    assert st["error_games"] == 0 and st["games"] > 0 and len(tm) > 0
+    n0 = (cells == 1).sum(1)
+    n1 = (cells == 2).sum(1)
+    assert ((n0 - n1 == tm) & ((tm == 0) | (tm == 1))).all()       # player 0 moves first, alternating
+    assert (pol[cells != 0] == 0).all()
+    s = pol.sum(1)
+    assert ((s > 0.9) & (s < 1.0)).all()
+    ok = (np.isclose(rew, [1, -1]).all(1) | np.isclose(rew, [-1, 1]).all(1) | np.isclose(rew, [0, 0]).all(1))
+    assert ok.all()
+    # first rows of games are empty boards with 2*budget sims: sum = 2b/(2b+1)
+    first = (cells.sum(1) == 0)
+    assert first.any()
+    assert np.allclose(s[first], 2 * budget / (2 * budget + 1.0), atol=2e-5)
