@@ -48,6 +48,7 @@ struct az_ctx {
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
     float* head_p = nullptr;
+    float* head_pt = nullptr;                             // fused path: fc1 weights transposed [A][64]
     size_t conv_layer_elems = 0;
     uint8_t* tower_in = nullptr;                          // staging for az_tower_forward [Bmax][3][A]
     float *tower_pol = nullptr, *tower_val = nullptr;
@@ -174,6 +175,7 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27)); AZCHK(dalloc(c, &c->stem_b, c->C_pad));
         AZCHK(dalloc(c, &c->stem_wbf, (size_t)128 * 32));
         AZCHK(dalloc(c, &c->conv_wf, (size_t)2 * c->num_res * 9 * 128 * 128));
+        AZCHK(dalloc(c, &c->head_pt, (size_t)258 + 64 * (size_t)A + 64 + 128 + 2));
         c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED");
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
         AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
@@ -325,6 +327,18 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     memcpy(q, fc2w, sizeof(float) * 128); q += 128;
     memcpy(q, fc2b, sizeof(float) * 2);
     HIPCHK(hipMemcpy(c->head_p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    if (c->fused) {
+        std::vector<float> ht((size_t)258 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
+        for (int ch = 0; ch < C; ++ch) { ht[ch] = hp[ch]; ht[128 + ch] = hp[Cp + ch]; }
+        ht[256] = hp[2 * Cp]; ht[257] = hp[2 * Cp + 1];
+        for (int o = 0; o < 64; ++o)
+            for (int a2 = 0; a2 < A; ++a2) ht[258 + (size_t)a2 * 64 + o] = fc1w[(size_t)o * A + a2];
+        float* q2 = ht.data() + 258 + 64 * (size_t)A;
+        memcpy(q2, fc1b, sizeof(float) * 64); q2 += 64;
+        memcpy(q2, fc2w, sizeof(float) * 128); q2 += 128;
+        memcpy(q2, fc2b, sizeof(float) * 2);
+        HIPCHK(hipMemcpy(c->head_pt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+    }
     c->have_weights = true;
     return AZ_OK;
 }
@@ -344,10 +358,9 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled);
-        az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b, c->actX,
-                              B, N, Gd, 2 * c->num_res);
+        az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
+                              c->head_pt, pol_dev, val_dev, B, N, Gd, 2 * c->num_res);
         prof_end(c, on);
-        az_launch_heads(c->stream, c->prec, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }

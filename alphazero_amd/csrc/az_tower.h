@@ -12,7 +12,7 @@ void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsign
                        int C_pad, int M, int N, int Gd, int relu);
 void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                            const float* stem_b, const unsigned short* wpk, const float* bias,
-                           unsigned short* out, int B, int N, int Gd, int n_layers);
+                           const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers);
 void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,
                      float* value, int B, int N, int C_pad, int Gd);
 }

@@ -228,6 +228,7 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 // touches HBM.  A tile holds bpt = 256 / (N+1)^2 whole boards; no halo exchange.
 //   stem  : im2col of the u8 planes (K = 27 -> 32) + 2 MFMA k-steps
 //   block : conv1 -> ReLU -> LDS ; conv2 + fp32 residual -> ReLU -> LDS
+//   heads : policy softmax and value MLP straight from the LDS-resident activations
 #define I_STRIDE 80             // 32 k * 2 B + 16 B pad
 #define W_BUF_BYTES (128 * 256)  // one tap of weights: 128 rows x 128 k bf16
 typedef __attribute__((address_space(3))) void lds_void;
@@ -237,7 +238,8 @@ template <int PR>
 __global__ void __launch_bounds__(256)
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
-                      const float* __restrict__ bias, unsigned short* __restrict__ out,
+                      const float* __restrict__ bias, const float* __restrict__ hp,
+                      float* __restrict__ policy, float* __restrict__ value,
                       int B, int N, int Gd, int n_layers, int bpt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = N + 1, P = W * W, A = N * N;
@@ -435,11 +437,104 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         __syncthreads();
     }
 #undef STAGE_W
-    // final activations -> HBM rows for the heads kernel (coalesced 16-byte stores)
-    for (int i = tid; i < rows_here * 16; i += 256) {
-        const int r = i >> 4, cpiece = i & 15;
-        const uint4 v = *(const uint4*)(sA + (size_t)(Gd + r) * A_STRIDE + cpiece * 16);
-        *(uint4*)(out + ((size_t)(Gd + b0 * P + r)) * 128 + cpiece * 8) = v;
+    // ---- heads, on the activations still resident in LDS --------------------
+    // PolicyHead (network.hpp:51-60): 1x1 conv -> softmax over each board's N*N cells.
+    // ValueHead (network.hpp:75-83): 1x1 conv -> BN(1) -> ReLU -> fc1 -> ReLU -> fc2 -> softmax*2-1.
+    // hp (fp32): wp[128], wv[128] (BN folded), bp, bv, fc1 weights TRANSPOSED [A][64]
+    // (so the 64 outputs of one cell are one coalesced 256-byte read), fc1b[64], fc2w[2][64], fc2b[2].
+    {
+        float* s_logit = (float*)sB;                 // [256] the weight buffers are free now
+        float* s_u = s_logit + 256;                  // [256]
+        float* s_part = s_u + 256;                   // [4][64]
+        float* s_red = s_part + 256;                 // [8]
+        int* s_map = (int*)(s_red + 8);              // [A] cell -> padded-raster row
+        const float* wp = hp;
+        const float* wvv = hp + 128;
+        const float bp = hp[256], bvv = hp[257];
+        const float* fc1t = hp + 258;
+        const float* fc1b = fc1t + 64 * A;
+        const float* fc2w = fc1b + 64;
+        const float* fc2b = fc2w + 128;
+        const int r = tid;
+        const int pp = r % P, py = pp / W, px = pp % W;
+        const bool cell = r < rows_here && py < N && px < N;
+        float sp = 0.f, sv = 0.f;
+        if (cell) {
+            const unsigned char* row = sA + (size_t)(Gd + r) * A_STRIDE;
+#pragma unroll 4
+            for (int c = 0; c < 128; c += 8) {
+                const uint4 v = *(const uint4*)(row + c * 2);
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float lo = Prec<PR>::from16((unsigned short)(u[t] & 0xFFFFu));
+                    const float hi = Prec<PR>::from16((unsigned short)(u[t] >> 16));
+                    sp += lo * wp[c + 2 * t] + hi * wp[c + 2 * t + 1];
+                    sv += lo * wvv[c + 2 * t] + hi * wvv[c + 2 * t + 1];
+                }
+            }
+        }
+        s_logit[r] = cell ? sp + bp : -3.4e38f;
+        s_u[r] = cell ? fmaxf(sv + bvv, 0.f) : 0.f;
+        for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
+        __syncthreads();
+        // softmax over each board's cells, reductions in a fixed order (deterministic bits)
+        const int base = (r / P) * P;
+        float mx, sum;
+        if (bpt == 1) {                              // one board per tile: block-wide reduce
+            float m = s_logit[r];
+            for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+            if (lane == 0) s_red[wv] = m;
+            __syncthreads();
+            mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+            const float e = cell ? expf(s_logit[r] - mx) : 0.f;
+            float t = e;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2, 64);
+            if (lane == 0) s_red[4 + wv] = t;
+            __syncthreads();
+            sum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            if (cell) policy[(size_t)b0 * A + py * N + px] = e / sum;
+        } else {                                     // several small boards per tile
+            mx = -3.4e38f;
+            for (int k = 0; k < P; ++k) mx = fmaxf(mx, s_logit[base + k]);
+            const float e = cell ? expf(s_logit[r] - mx) : 0.f;
+            __syncthreads();
+            s_logit[r] = e;
+            __syncthreads();
+            sum = 0.f;
+            for (int k = 0; k < P; ++k) sum += s_logit[base + k];
+            if (cell) policy[(size_t)(b0 + r / P) * A + py * N + px] = e / sum;
+        }
+        for (int bi = 0; bi < nb_here; ++bi) {       // value head, one board at a time
+            const int o = tid & 63, part = tid >> 6;
+            float acc1 = 0.f;
+            int a = part;
+            for (; a + 28 < A; a += 32) {            // 8 independent loads in flight per lane
+                float wv8[8], uv8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) wv8[t] = fc1t[(a + 4 * t) * 64 + o];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) uv8[t] = s_u[bi * P + s_map[a + 4 * t]];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc1 += wv8[t] * uv8[t];
+            }
+            for (; a < A; a += 4) acc1 += fc1t[a * 64 + o] * s_u[bi * P + s_map[a]];
+            s_part[part * 64 + o] = acc1;
+            __syncthreads();
+            if (tid < 64) {
+                const float f = fmaxf(s_part[tid] + s_part[64 + tid] + s_part[128 + tid] + s_part[192 + tid] + fc1b[tid], 0.f);
+                float z0 = fc2w[tid] * f, z1 = fc2w[64 + tid] * f;
+                for (int o2 = 32; o2 > 0; o2 >>= 1) { z0 += __shfl_xor(z0, o2, 64); z1 += __shfl_xor(z1, o2, 64); }
+                if (tid == 0) {
+                    z0 += fc2b[0]; z1 += fc2b[1];
+                    const float m2 = fmaxf(z0, z1);
+                    const float e0 = expf(z0 - m2), e1 = expf(z1 - m2);
+                    value[2 * (size_t)(b0 + bi)] = e0 / (e0 + e1) * 2.f - 1.f;
+                    value[2 * (size_t)(b0 + bi) + 1] = e1 / (e0 + e1) * 2.f - 1.f;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -555,13 +650,13 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short*
 
 extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                                       const float* stem_b, const unsigned short* wpk, const float* bias,
-                                      unsigned short* out, int B, int N, int Gd, int n_layers) {
+                                      const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers) {
     const int P = (N + 1) * (N + 1);
     const int bpt = TILE_M / P;
     const int tiles = (B + bpt - 1) / bpt;
     const size_t sm = (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)bpt * 3 * N * N + 16;
     BY_PREC(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
-            out, B, N, Gd, n_layers, bpt);
+            hp, policy, value, B, N, Gd, n_layers, bpt);
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,

@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="split the GPU's games over this many engine contexts (own stream each) so that one "
+                         "context's tree kernel overlaps another's tower")
     ap.add_argument("--full-games", type=float, default=0.0,
                     help="after the timed region keep playing for this many seconds and report finished games/hour")
     args = ap.parse_args()
@@ -92,8 +95,11 @@ def main():
     N, K, G, budget = args.board, 5, args.games, args.budget
     Cs = synth.NETCONFIG2
     prec = capi.AZ_PREC_FP16 if args.precision == "fp16" else capi.AZ_PREC_BF16
-    eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
-                      device=local_rank, game_slot_base=rank * G, precision=prec)
+    NC = args.contexts
+    assert G % NC == 0
+    engs = [capi.Engine(N, K, G // NC, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
+                        device=local_rank, game_slot_base=rank * G + i * (G // NC), precision=prec) for i in range(NC)]
+    eng = engs[0]
     # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
     nw = eng.weights_size()
     if world > 1:
@@ -102,23 +108,37 @@ def main():
             wt.copy_(torch.from_numpy(synth.make_blob(N, 3, Cs, 0)))
         dist.broadcast(wt, 0)
         torch.cuda.synchronize()
-        eng.load_weights_dev(wt.data_ptr(), nw)
+        for e in engs:
+            e.load_weights_dev(wt.data_ptr(), nw)
     else:
-        eng.load_weights(synth.make_blob(N, 3, Cs, 0))
+        blob = synth.make_blob(N, 3, Cs, 0)
+        for e in engs:
+            e.load_weights(blob)
+
+    def run(rounds):
+        # launches are asynchronous: interleave the contexts in slices so every stream stays fed
+        done = 0
+        while done < rounds:
+            k = min(16, rounds - done)
+            for e in engs:
+                e.selfplay_run(k)
+            done += k
 
     def barrier():
-        eng.sync()
+        for e in engs:
+            e.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.selfplay_begin(budget)
-    eng.selfplay_run(args.warmup)
+    for e in engs:
+        e.selfplay_begin(budget)
+    run(args.warmup)
     eng.profile_enable(8)
     barrier()
     t0 = time.perf_counter()
-    eng.selfplay_run(args.steps)
+    run(args.steps)
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
@@ -126,7 +146,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     prof = eng.profile_read()
-    st = eng.stats()
+    sts = [e.stats() for e in engs]
+    st = {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
     if st["error_games"]:
         raise SystemExit("tree arena overflow in %d games" % st["error_games"])
     games_info = None
@@ -136,11 +157,12 @@ def main():
         t1 = time.perf_counter()
         g0, m0 = st["games"], st["moves"]
         while time.perf_counter() - t1 < args.full_games:
-            eng.selfplay_run(budget)
-            eng.replay_drain(1 << 15)
-            eng.sync()
+            run(budget)
+            for e in engs:
+                e.replay_drain(1 << 15)
         el2 = time.perf_counter() - t1
-        st2 = eng.stats()
+        sts2 = [e.stats() for e in engs]
+        st2 = {k: sum(x[k] for x in sts2) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts2) for k in sts2[0]}
         games_info = {"seconds": el2, "games": st2["games"] - g0, "moves": st2["moves"] - m0,
                       "games_per_hour": (st2["games"] - g0) / el2 * 3600.0,
                       "mean_game_length": (st2["moves"] - m0) / max(1, st2["games"] - g0),
@@ -153,7 +175,7 @@ def main():
         conv_flops = 2.0 * 9 * A * C * C * G               # one 3x3 conv over G boards, real cells only
         kernel = "az_conv3x3_kernel"
         if eng.tower_is_fused():                           # stem + all 2*num_res convs in one launch
-            conv_flops = conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * G
+            conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * G) / NC   # per launch of one context
             kernel = "az_tower_fused_kernel"
         conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
         line = {
@@ -162,7 +184,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
                                    "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
-                       "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world},
+                       "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world,
+                       "contexts_per_gpu": NC},
             "moves_per_s": sims / el / budget,
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": conv_tflops,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
@@ -174,7 +197,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, N, K, budget, 16)
         print(json.dumps(line), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
