@@ -41,6 +41,13 @@ template <> struct Prec<0> {
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // relu + round-to-nearest-even pack of two values: v_max x2 + one v_cvt_pk_bf16_f32
+    static __device__ __forceinline__ unsigned pack2_relu(float a, float b) {
+        typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 f = {fmaxf(a, 0.f), fmaxf(b, 0.f)};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
+    }
 };
 template <> struct Prec<1> {
     typedef f16x8 vec;
@@ -52,6 +59,13 @@ template <> struct Prec<1> {
     static __device__ __forceinline__ float from16(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    // relu + saturation in one v_med3_f32 each, then one packed convert
+    static __device__ __forceinline__ unsigned pack2_relu(float a, float b) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 f = {__builtin_amdgcn_fmed3f(a, 0.f, 65504.f), __builtin_amdgcn_fmed3f(b, 0.f, 65504.f)};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
     }
 };
 
@@ -325,8 +339,10 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = Prec<PR>::mfma(wa[i], xb[j], acc[i][j]);
     }
-    // epilogue shared by the stem and every conv: mode 0 = stem / conv1 (no skip), 1 = conv2 (+ residual)
-    auto epilogue = [&](const float* bptr, int mode) {
+    // epilogue shared by the stem and every conv.  keep: the result also becomes the
+    // fp32 residual (stem output and every conv2 output); skip: add the residual first.
+    const unsigned keepmask[2] = {real[0] ? 0xFFFFFFFFu : 0u, real[1] ? 0xFFFFFFFFu : 0u};
+    auto epilogue = [&](const float* bptr, bool skip, bool keep) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             unsigned char* rowp = sA + (size_t)(Gd + 64 * wv + 32 * j + l31) * A_STRIDE + 8 * h;
@@ -337,21 +353,17 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                     const float4 bv = *(const float4*)(bptr + 32 * i + 8 * q + 4 * h);
                     float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
                     float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
-                    if (mode == 1) {
+                    if (skip) {
                         v0 += res[i][j][4 * q + 0]; v1 += res[i][j][4 * q + 1];
                         v2 += res[i][j][4 * q + 2]; v3 += res[i][j][4 * q + 3];
                     }
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    if (!real[j]) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
-                    if (mode != 2) {
-                        if (mode == 1 || bptr == stem_b) {
-                            res[i][j][4 * q + 0] = v0; res[i][j][4 * q + 1] = v1;
-                            res[i][j][4 * q + 2] = v2; res[i][j][4 * q + 3] = v3;
-                        }
+                    if (keep) {              // residual of padding rows only ever feeds padding rows
+                        res[i][j][4 * q + 0] = fmaxf(v0, 0.f); res[i][j][4 * q + 1] = fmaxf(v1, 0.f);
+                        res[i][j][4 * q + 2] = fmaxf(v2, 0.f); res[i][j][4 * q + 3] = fmaxf(v3, 0.f);
                     }
-                    uint2 o;
-                    o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
-                    o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
+                    uint2 o;                 // the LDS copy is what neighbours read: padding rows must be 0
+                    o.x = Prec<PR>::pack2_relu(v0, v1) & keepmask[j];
+                    o.y = Prec<PR>::pack2_relu(v2, v3) & keepmask[j];
                     *(uint2*)(rowp + (32 * i + 8 * q) * 2) = o;
                     acc[i][j][4 * q + 0] = 0.f; acc[i][j][4 * q + 1] = 0.f;
                     acc[i][j][4 * q + 2] = 0.f; acc[i][j][4 * q + 3] = 0.f;
@@ -359,7 +371,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         }
     };
     __syncthreads();                                         // every wave is done with sI / sW
-    epilogue(stem_b, 0);
+    epilogue(stem_b, false, true);
 
     // Weight stream: one chunk = one 3x3 tap = [n=128][k=128] bf16 = 32 KB,
     // copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no
@@ -433,7 +445,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             __syncthreads();                                 // next tap landed (vmcnt(0)), this one fully read
         }
         // all waves have finished reading this layer's input: overwrite it in place
-        epilogue(bias + (size_t)L * 128, L & 1);
+        if (L & 1) epilogue(bias + (size_t)L * 128, true, true);
+        else epilogue(bias + (size_t)L * 128, false, false);
         __syncthreads();
     }
 #undef STAGE_W
