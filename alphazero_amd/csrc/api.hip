@@ -289,10 +289,10 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
             cb[(size_t)L * Cp + co] = (float)(((double)cv.b[co] - bb.rm[co]) * s + bb.b[co]);
             const int nb = co / 128, n = co % 128;
             for (int ci = 0; ci < C; ++ci) {
-                const int sc = ci / 128, kc = (ci % 128) / 64, k = ci % 64;
+                const int sc = ci / 128, k = ci % 128;
                 for (int tap = 0; tap < 9; ++tap) {
-                    const size_t chunk = (((size_t)nb * nblk + sc) * 9 + tap) * 2 + kc;
-                    dst[chunk * (128 * 64) + (size_t)n * 64 + k] =
+                    const size_t chunk = ((size_t)nb * nblk + sc) * 9 + tap;     // [nb][sc][tap][n][k]
+                    dst[chunk * (128 * 128) + (size_t)n * 128 + k] =
                         to16((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
                 }
             }

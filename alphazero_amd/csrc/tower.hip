@@ -1,11 +1,14 @@
 // tower.hip -- the ResNet policy/value tower (PVNetwork::forward, eval mode,
 // network.hpp:117-123) as hand-written gfx950 kernels.
 //
+//   az_tower_fused_kernel  the whole tower (stem, all ResBlocks, both heads) in ONE
+//                     launch, activations resident in LDS (C <= 128, (N+1)^2 <= 256)
 //   az_stem_kernel    ConvBlock (network.hpp:15-17): 3x3 conv on the u8 planes,
-//                     BN folded, ReLU; exact fp32 VALU (K = 27 is too thin for MFMA)
-//   az_conv3x3_kernel ResBlock convolutions (network.hpp:32-38) as implicit GEMM
-//                     on v_mfma_f32_32x32x16_bf16: D[ch][pos] = sum_k W[ch][k] X[k][pos]
-//   az_heads_kernel   PolicyHead + ValueHead (network.hpp:51-60,75-83), fp32
+//                     BN folded, ReLU; fp32 VALU                       } per-layer
+//   az_conv3x3_kernel ResBlock convolutions (network.hpp:32-38) as      } path for
+//                     implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}:  } wider or
+//                     D[ch][pos] = sum_k W[ch][k] X[k][pos]             } larger
+//   az_heads_kernel   PolicyHead + ValueHead (network.hpp:51-60,75-83)  } shapes
 //
 // Activation layout in HBM: bf16 rows [guard + M_pad + guard][C_pad]; one row
 // per board position in a zero-padded (N+1)x(N+1) raster (column N and row N
@@ -21,8 +24,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define TILE_M 256
 #define A_STRIDE 272            // 128 ch * 2 B + 16 B pad: conflict-free ds_read_b128
-#define B_STRIDE 144            // 64 k * 2 B + 16 B pad
-#define B_BUF_BYTES (128 * B_STRIDE)
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
@@ -113,13 +114,21 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
 }
 
 // ---------------------------------------------------------------- conv 3x3
+// Per-layer implicit GEMM (any C multiple of 128, any N <= 21): used where the
+// fused kernel does not apply (C = 256, or boards larger than one tile).
 // grid (M_pad/256, C_pad/128), 256 threads = 4 waves; wave w owns positions
 // [64w, 64w+64) of the tile and all 128 output channels of the column block:
 // 4x2 accumulator tiles of 32(ch) x 32(pos).
-// Weights arrive pre-packed as 16 KB chunks [nb][sc][tap][kc][n=128][k=64]
-// (bf16, BN scale folded), streamed through a double-buffered LDS stage;
-// the activation tile with its halo is staged once per 128-channel slab and
-// reused by all 9 taps.
+// Weights are pre-packed as 32 KB chunks [nb][sc][tap][n=128][k=128] (BN scale
+// folded) and copied global -> LDS by global_load_lds into a double buffer whose
+// image is XOR-swizzled through the source address (16-byte piece c of row n at
+// piece c ^ (n & 15)).  The activation tile with its halo is staged once per
+// 128-channel slab and reused by all 9 taps; the output goes back through LDS so
+// that HBM sees whole 256-byte rows.
+#define W_BUF_BYTES (128 * 256)  // one tap of weights: 128 rows x 128 k, 16-bit
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) void gl_void;
+
 template <int PR>
 __global__ void __launch_bounds__(256)
 az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
@@ -137,8 +146,8 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
     const int m0 = blockIdx.x * TILE_M;
     const int nb = blockIdx.y;
     const int n_sc = C_pad / 128;
-    const int total = n_sc * 18;
-    const unsigned short* wbase = wpk + (size_t)nb * n_sc * 18 * (128 * 64);
+    const int total = n_sc * 9;
+    const unsigned short* wbase = wpk + (size_t)nb * n_sc * 9 * (128 * 128);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -148,15 +157,12 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // next weight chunk in flight: four named registers (an array captured by a
-    // lambda is demoted to scratch, which exposes the full load latency)
-    uint4 w0, w1, w2, w3;
-    unsigned char* const sBst = sB + (tid >> 3) * B_STRIDE + (tid & 7) * 16;   // idx = p*256 + tid
-#define LOAD_W(c) do { const uint4* src_ = (const uint4*)(wbase + (size_t)(c) * (128 * 64)) + tid; \
-        w0 = src_[0]; w1 = src_[256]; w2 = src_[512]; w3 = src_[768]; } while (0)
-#define STORE_W(buf) do { unsigned char* d_ = sBst + (buf) * B_BUF_BYTES; \
-        *(uint4*)(d_) = w0; *(uint4*)(d_ + 32 * B_STRIDE) = w1; \
-        *(uint4*)(d_ + 64 * B_STRIDE) = w2; *(uint4*)(d_ + 96 * B_STRIDE) = w3; } while (0)
+    const int st_row = tid >> 4;
+    const int st_src = st_row * 128 + (((tid & 15) ^ (st_row & 15)) << 3);
+    unsigned char* const st_dst = sB + (tid & ~63) * 16;
+#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_global_load_lds( \
+        (gl_void*)(wbase + (size_t)(g_) * (128 * 128) + (p_) * (16 * 128) + st_src), \
+        (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, 0, 0)
     auto stage_a = [&](int sc) {
         for (int r = tid >> 4; r < a_rows; r += 16) {
             const uint4 v = *(const uint4*)(in + (size_t)(m0 + r) * C_pad + sc * 128 + (tid & 15) * 8);
@@ -165,50 +171,77 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
     };
 
     stage_a(0);
-    LOAD_W(0);
-    STORE_W(0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) STAGE_W(0, 0, p);
     __syncthreads();
 
     const int posrow0 = Gd + 64 * wv + l31;            // LDS row of this lane's position, tile j adds 32
-    for (int c = 0; c < total; ++c) {
-        const int cc = c % 18;
-        const int tap = cc >> 1, kc = cc & 1;
+    const int swz = l31 & 15;
+    for (int g = 0; g < total; ++g) {
+        const int tap = g % 9;
         const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
-        if (c + 1 < total) LOAD_W(c + 1);
-        const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + kc * 128 + h * 16;
-        const unsigned char* bB = sB + (c & 1) * B_BUF_BYTES + l31 * B_STRIDE + h * 16;
+        const bool more = g + 1 < total;
+        const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + h * 16;
+        const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
+        typename Prec<PR>::vec fx[2][2], fw[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            typename Prec<PR>::vec xb[2], wa[4];
+        for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xb[j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + ks * 32);
+        for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wa[i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * B_STRIDE + ks * 32);
+        for (int ks = 0; ks < 8; ++ks) {
+            if (more && ks < 4) { STAGE_W(g + 1, (g + 1) & 1, 2 * ks); STAGE_W(g + 1, (g + 1) & 1, 2 * ks + 1); }
+            if (ks < 7) {
+                const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + wo);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = Prec<PR>::mfma(wa[i], xb[j], acc[i][j]);
-        }
-        if (c + 1 < total) {
-            if ((c + 1) % 18 == 0) {                   // next 128-channel slab of the input
-                __syncthreads();
-                stage_a((c + 1) / 18);
+                    acc[i][j] = Prec<PR>::mfma(fw[ks & 1][i], fx[ks & 1][j], acc[i][j]);
+            if (ks < 7) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             }
-            STORE_W((c + 1) & 1);
+        }
+        __syncthreads();                               // next tap landed, this one fully read
+        if (more && (g + 1) % 9 == 0) {                // next 128-channel slab of the input
+            stage_a((g + 1) / 9);
+            __syncthreads();
+        }
+    }
+#undef STAGE_W
+
+    // epilogue through LDS (rows 0..255 of sA, this column block's 128 channels):
+    // coalesced residual load -> + bias (+ residual), ReLU, zero padding rows -> coalesced store
+    if (resid) {
+        for (int i = tid; i < TILE_M * 16; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            *(uint4*)(sA + r * A_STRIDE + c * 16) =
+                *(const uint4*)(resid + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8);
         }
         __syncthreads();
     }
-#undef LOAD_W
-#undef STORE_W
-
-    // epilogue: + bias (+ residual), ReLU, zero the padding raster, bf16 store
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int m = m0 + 64 * wv + 32 * j + l31;
+        const int rr = 64 * wv + 32 * j + l31;
+        const int m = m0 + rr;
         const int p = m % P;
-        const bool real = m < M && (p / W) < N && (p % W) < N;
-        const size_t rowoff = (size_t)(Gd + m) * C_pad + nb * 128 + 4 * h;
+        const unsigned keep = (m < M && (p / W) < N && (p % W) < N) ? 0xFFFFFFFFu : 0u;
+        unsigned char* rowp = sA + rr * A_STRIDE + 8 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -218,18 +251,24 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
                 float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
                 float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
                 if (resid) {
-                    const uint2 rv = *(const uint2*)(resid + rowoff + cch);
+                    const uint2 rv = *(const uint2*)(rowp + cch * 2);
                     v0 += Prec<PR>::from16((unsigned short)(rv.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(rv.x >> 16));
                     v2 += Prec<PR>::from16((unsigned short)(rv.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(rv.y >> 16));
                 }
-                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                uint2 o = make_uint2(0u, 0u);
-                if (real) {
+                uint2 o;
+                if (relu) { o.x = Prec<PR>::pack2_relu(v0, v1); o.y = Prec<PR>::pack2_relu(v2, v3); }
+                else {
                     o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
                     o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                 }
-                *(uint2*)(out + rowoff + cch) = o;
+                o.x &= keep; o.y &= keep;
+                *(uint2*)(rowp + cch * 2) = o;
             }
+    }
+    __syncthreads();
+    for (int i = tid; i < TILE_M * 16; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sA + r * A_STRIDE + c * 16);
     }
 }
 
@@ -244,9 +283,6 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 //   block : conv1 -> ReLU -> LDS ; conv2 + fp32 residual -> ReLU -> LDS
 //   heads : policy softmax and value MLP straight from the LDS-resident activations
 #define I_STRIDE 80             // 32 k * 2 B + 16 B pad
-#define W_BUF_BYTES (128 * 256)  // one tap of weights: 128 rows x 128 k bf16
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) void gl_void;
 
 template <int PR>
 __global__ void __launch_bounds__(256)
@@ -632,7 +668,7 @@ az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------ host launchers
-static inline size_t conv_smem(int Gd) { return (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * B_BUF_BYTES; }
+static inline size_t conv_smem(int Gd) { return (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES; }
 
 extern "C" int az_tower_configure(void) {
     hipError_t e = hipSuccess;
