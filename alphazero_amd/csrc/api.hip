@@ -98,8 +98,11 @@ static size_t weights_size(int N, int c_in, const int* Cs, int n_Cs) {
     return s;
 }
 
+static int ctx_build(az_ctx* c, const az_config* cfg);
+
 extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
     if (!out || !cfg) return fail(AZ_E_ARG, "null argument");
+    *out = nullptr;
     if (cfg->N < 3 || cfg->N * cfg->N > 512 - 64) return fail(AZ_E_ARG, "board side %d unsupported (3..21)", cfg->N);
     if (cfg->K < 2 || cfg->K > 8 || cfg->K > cfg->N) return fail(AZ_E_ARG, "win length %d unsupported (2..8, <= N)", cfg->K);
     if (cfg->G < 1) return fail(AZ_E_ARG, "G must be >= 1");
@@ -118,6 +121,18 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
     HIPCHK(hipSetDevice(cfg->device));
     az_ctx* c = new az_ctx;
     c->cfg = *cfg;
+    const int rc = ctx_build(c, cfg);
+    if (rc != AZ_OK) {                       // free whatever was allocated before the failure
+        const std::string keep = g_err;
+        az_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return AZ_OK;
+}
+
+static int ctx_build(az_ctx* c, const az_config* cfg) {
     const int N = cfg->N, A = N * N, G = cfg->G;
     c->A = A; c->W = N + 1; c->P = c->W * c->W; c->Gd = N + 2;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -186,17 +201,16 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         if (az_tower_configure() != 0) return fail(AZ_E_HIP, "tower kernel LDS configuration failed");
     }
     HIPCHK(hipDeviceSynchronize());
-    *out = c;
     return AZ_OK;
 }
 
 extern "C" int az_ctx_destroy(az_ctx* c) {
     if (!c) return AZ_OK;
     (void)hipSetDevice(c->cfg.device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return AZ_OK;
 }
@@ -532,8 +546,8 @@ static int check_errors(az_ctx* c) {
 
 extern "C" int az_search_begin(az_ctx* c, int budget) {
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (budget > c->d.budget && c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
-        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget %d", budget, c->d.budget);
+    if (c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
+        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget (arena sized for %d nodes)", budget, c->d.node_cap);
     c->mode = AZ_MODE_SEARCH;
     az_launch_begin(c->stream, &c->d, budget);
     HIPCHK(hipGetLastError());
@@ -631,8 +645,8 @@ extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int
 extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "self-play needs a device evaluator");
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (4 * budget + 64 > c->d.node_cap && c->cfg.node_cap == 0)
-        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget %d", budget, c->d.budget);
+    if (c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
+        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget (arena sized for %d nodes)", budget, c->d.node_cap);
     c->d.budget = budget > 1 ? budget : 1;
     c->mode = AZ_MODE_SELFPLAY;
     HIPCHK(hipMemsetAsync(c->d.counters, 0, 16 * sizeof(unsigned long long), c->stream));

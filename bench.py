@@ -88,7 +88,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -102,7 +103,7 @@ def main():
     eng = engs[0]
     # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
     nw = eng.weights_size()
-    if world > 1:
+    if use_dist:
         wt = torch.empty(nw, dtype=torch.float32, device="cuda")
         if rank == 0:
             wt.copy_(torch.from_numpy(synth.make_blob(N, 3, Cs, 0)))
@@ -128,7 +129,7 @@ def main():
         for e in engs:
             e.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -141,7 +142,7 @@ def main():
     run(args.steps)
     barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -199,7 +200,7 @@ def main():
         print(json.dumps(line), flush=True)
     for e in engs:
         e.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
