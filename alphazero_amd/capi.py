@@ -23,7 +23,7 @@ EXPORTS = [
     "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
-    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused",
+    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step",
 ]
 
 
@@ -269,6 +269,14 @@ class Engine:
         cn, tn = C.c_int64(), C.c_int64()
         _chk(load().az_profile_read(self.h, C.byref(ca), C.byref(cn), C.byref(ta), C.byref(tn)))
         return dict(conv_avg_us=ca.value, conv_launches=cn.value, tree_avg_us=ta.value, tree_launches=tn.value)
+
+
+def host_env_step(N, K, cells, to_move, action):
+    cells = np.ascontiguousarray(cells, np.uint8).copy()
+    tm = C.c_int(int(to_move))
+    rew = np.zeros(2, np.float32)
+    rc = load().az_host_env_step(N, K, _ptr(cells), C.byref(tm), int(action), _ptr(rew))
+    return cells, tm.value, rew, rc
 
 
 def replay_symmetries(N, cells, to_move, policy):

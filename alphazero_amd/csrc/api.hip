@@ -746,6 +746,13 @@ extern "C" int az_profile_read(az_ctx* c, double* conv_avg_us, int64_t* conv_lau
     return AZ_OK;
 }
 
+// Host twin of the device rules (az_rules.h), exposed so that the CPU test-suite
+// can check it against the oracle without a GPU.
+extern "C" int az_host_env_step(int N, int K, uint8_t* cells, int* to_move, int action, float* reward) {
+    if (N < 1 || K < 1 || !cells || !to_move || !reward) return fail(AZ_E_ARG, "null argument");
+    return az_rules_step(N, K, cells, to_move, action, reward);
+}
+
 // replay.hpp:80-112 (host helper): rot90(r,{1,2}) then .flip(1), r = 0..3.
 extern "C" int az_replay_symmetries(int N, const uint8_t* cells, int to_move, const float* policy,
                                     uint8_t* states_out, float* policies_out) {

@@ -298,7 +298,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
     unsigned char* sI = sB;                                  // stem im2col [256][I_STRIDE]
     unsigned char* sW = sB + TILE_M * I_STRIDE;              // stem weights [128][I_STRIDE]
-    uint8_t* sP = sB + 2 * W_BUF_BYTES;                      // planes of this tile's boards
+    float* sBias = (float*)(sB + 2 * W_BUF_BYTES);           // [n_layers + 1][128]: stem bias, then every conv's
+    uint8_t* sP = (uint8_t*)(sBias + (n_layers + 1) * 128);  // planes of this tile's boards
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -310,6 +311,9 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     // zero the activation tile (guards and idle rows stay zero for the whole kernel)
     for (int i = tid; i < a_rows * (A_STRIDE / 16); i += 256) *(uint4*)(sA + i * 16) = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < nb_here * 3 * A; i += 256) sP[i] = planes[(size_t)b0 * 3 * A + i];
+    // all biases into LDS once: the per-layer epilogue then never waits on HBM/L2
+    for (int i = tid; i < 128; i += 256) sBias[i] = stem_b[i];
+    for (int i = tid; i < n_layers * 128; i += 256) sBias[128 + i] = bias[i];
     for (int i = tid; i < 128 * 4; i += 256)
         *(uint4*)(sW + (i >> 2) * I_STRIDE + (i & 3) * 16) = *(const uint4*)(stem_w + (size_t)i * 8);
     __syncthreads();
@@ -407,7 +411,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         }
     };
     __syncthreads();                                         // every wave is done with sI / sW
-    epilogue(stem_b, false, true);
+    epilogue(sBias, false, true);
 
     // Weight stream: one chunk = one 3x3 tap = [n=128][k=128] bf16 = 32 KB,
     // copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no
@@ -481,8 +485,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             __syncthreads();                                 // next tap landed (vmcnt(0)), this one fully read
         }
         // all waves have finished reading this layer's input: overwrite it in place
-        if (L & 1) epilogue(bias + (size_t)L * 128, true, true);
-        else epilogue(bias + (size_t)L * 128, false, false);
+        if (L & 1) epilogue(sBias + (L + 1) * 128, true, true);
+        else epilogue(sBias + (L + 1) * 128, false, false);
         __syncthreads();
     }
 #undef STAGE_W
@@ -703,7 +707,8 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     const int P = (N + 1) * (N + 1);
     const int bpt = TILE_M / P;
     const int tiles = (B + bpt - 1) / bpt;
-    const size_t sm = (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)bpt * 3 * N * N + 16;
+    const size_t sm = (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)(n_layers + 1) * 128 * 4 +
+                      (size_t)bpt * 3 * N * N + 16;
     BY_PREC(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
             hp, policy, value, B, N, Gd, n_layers, bpt);
 }

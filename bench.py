@@ -179,6 +179,15 @@ def main():
             conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * G) / NC   # per launch of one context
             kernel = "az_tower_fused_kernel"
         conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
+        # (tools/profile_bench.sh); only valid for the workload they were collected on
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj) and (N, G, budget, NC) == (15, 512, 800, 1):
+            try:
+                traffic = json.load(open(tj))["kernels"][kernel]["traffic_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
         line = {
             "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -190,7 +199,7 @@ def main():
             "moves_per_s": sims / el / budget,
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": conv_tflops,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": None, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
+                         "traffic": traffic, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
                          "flops_per_launch": conv_flops,
                          "tree_round_avg_us": prof["tree_avg_us"]},
         }

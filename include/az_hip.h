@@ -151,6 +151,10 @@ int az_selfplay_run(az_ctx*, int rounds);
 int az_replay_drain(az_ctx*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
 int az_get_stats(az_ctx*, az_stats*);
 
+/* Env::step on the host (the rules the C++ Env shim and az_env_load use; same
+ * rules as the device kernels): returns 1 done, 0 running, AZ_E_ARG illegal. */
+int az_host_env_step(int N, int K, uint8_t* cells, int* to_move, int action, float* reward);
+
 /* Measurement hook (no counterpart in the reference, whose only timers are the
  * verbosity-3 chrono buckets of mcts.hpp:187-201): HIP events on the context's
  * stream around every 3x3-convolution launch and every tree-round launch of

@@ -44,3 +44,21 @@ def test_replay_symmetries_host_helper_matches_oracle_and_torch():
         assert np.array_equal(so[v], sr.numpy()) and np.array_equal(po[v], pr[0].numpy())
         assert np.array_equal(so[v + 1], sr.flip(1).numpy()) and np.array_equal(po[v + 1], pr.flip(1)[0].numpy())
         v += 2
+
+
+def test_host_rules_match_oracle_on_random_playouts():
+    import azo
+    rng = np.random.default_rng(3)
+    for N, K in ((3, 3), (7, 4), (9, 5), (15, 5)):
+        for _ in range(20):
+            ca, ta = azo.env_reset(N)
+            cb, tb = ca.copy(), 0
+            while True:
+                a = int(rng.choice(azo.env_legal(N, ca)))
+                ca, ta, ra, da = azo.env_step(N, K, ca, ta, a)
+                cb, tb, rb, db = capi.host_env_step(N, K, cb, tb, a)
+                assert np.array_equal(ca, cb) and ta == tb and np.array_equal(ra, rb) and da == db
+                if da:
+                    break
+            # an occupied cell is rejected by both
+            assert capi.host_env_step(N, K, cb, tb, a)[3] < 0 and azo.env_step(N, K, ca, ta, a)[3] < 0
