@@ -374,11 +374,39 @@ static int cmd_bench(int argc, char** argv) {
     _exit(0);
 }
 
+/* --------------------------------------------------------------- replayio -- */
+/* The trainer's on-disk buffer (replay.hpp:241-274 save, :163-208 load): three
+ * tensors through torch::save / torch::load.  replay.hpp itself cannot be
+ * compiled here (needs cppzmq), so the two calls it makes are made directly. */
+static int cmd_replayio(int argc, char** argv) {
+    if (argc < 4) { fprintf(stderr, "replayio write|read dir\n"); return 2; }
+    const std::string mode = argv[2], dir = argv[3];
+    if (mode == "write") {
+        const int n = 5, N = 3;
+        auto s = (torch::arange(n * 3 * N * N) % 3 == 0).to(torch::kUInt8).reshape({n, 3, N, N});
+        auto p = (torch::arange(n * N * N, torch::kFloat32) / 100.0).reshape({n, 1, N, N});
+        auto r = torch::tensor({1.f, -1.f, -1.f, 1.f, 0.f, 0.f, 1.f, -1.f, 0.f, 0.f}).reshape({n, 2});
+        torch::save(s, dir + "/replay.state");
+        torch::save(p, dir + "/replay.policy");
+        torch::save(r, dir + "/replay.reward");
+        return 0;
+    }
+    torch::Tensor s, p, r;
+    torch::load(s, dir + "/replay.state");
+    torch::load(p, dir + "/replay.policy");
+    torch::load(r, dir + "/replay.reward");
+    if (s.dtype() != torch::kUInt8 || p.dtype() != torch::kFloat32 || r.dtype() != torch::kFloat32) return 3;
+    printf("%ld %ld %ld %ld | %ld %.6f %.6f\n", (long)s.size(0), (long)s.size(1), (long)p.size(1), (long)r.size(1),
+           (long)s.sum().item<int64_t>(), p.sum().item<double>(), r.abs().sum().item<double>());
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: az_ref tower|mcts|bench ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: az_ref tower|mcts|bench|replayio ...\n"); return 2; }
     const std::string c = argv[1];
     if (c == "tower") return cmd_tower(argc, argv);
     if (c == "mcts") return cmd_mcts(argc, argv);
     if (c == "bench") return cmd_bench(argc, argv);
+    if (c == "replayio") return cmd_replayio(argc, argv);
     return 2;
 }
