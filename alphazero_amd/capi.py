@@ -36,7 +36,7 @@ class AzConfig(C.Structure):
         ("device", C.c_int), ("N", C.c_int), ("K", C.c_int), ("G", C.c_int), ("n_Cs", C.c_int),
         ("Cs", C.c_int * AZ_MAX_LAYERS), ("vl", C.c_float), ("c_puct", C.c_float), ("node_cap", C.c_int),
         ("max_budget", C.c_int), ("eval_mode", C.c_int), ("noise_mode", C.c_int), ("precision", C.c_int),
-        ("seed", C.c_uint64), ("game_slot_base", C.c_int),
+        ("seed", C.c_uint64), ("game_slot_base", C.c_int), ("leaves_per_round", C.c_int),
     ]
 
 
@@ -44,7 +44,8 @@ class AzStats(C.Structure):
     _fields_ = [
         ("sims", C.c_int64), ("evals", C.c_int64), ("rounds", C.c_int64), ("moves", C.c_int64),
         ("games", C.c_int64), ("replay_rows", C.c_int64), ("replay_dropped", C.c_int64),
-        ("max_nodes", C.c_int32), ("max_edges", C.c_int32), ("error_games", C.c_int32),
+        ("max_nodes", C.c_int32), ("max_edges", C.c_int32), ("error_games", C.c_int32), ("reserved", C.c_int32),
+        ("sims_backed_up", C.c_int64),
     ]
 
 
@@ -84,7 +85,7 @@ class Engine:
 
     def __init__(self, N, K, G, Cs=None, vl=3.0, c_puct=3.0, max_budget=800, node_cap=0,
                  eval_mode=AZ_EVAL_TOWER, noise_mode=AZ_NOISE_EXPLICIT, precision=AZ_PREC_BF16,
-                 seed=0, device=0, game_slot_base=0):
+                 seed=0, device=0, game_slot_base=0, leaves_per_round=1):
         L = load()
         cfg = AzConfig()
         cfg.device, cfg.N, cfg.K, cfg.G = device, N, K, G
@@ -96,6 +97,8 @@ class Engine:
         cfg.node_cap, cfg.max_budget = node_cap, max_budget
         cfg.eval_mode, cfg.noise_mode, cfg.precision = eval_mode, noise_mode, precision
         cfg.seed, cfg.game_slot_base = seed, game_slot_base
+        cfg.leaves_per_round = leaves_per_round
+        self.L = max(1, leaves_per_round)
         self.N, self.K, self.G, self.A = N, K, G, N * N
         self.Cs = Cs
         self.h = C.c_void_p()
@@ -181,8 +184,8 @@ class Engine:
         _chk(load().az_search_begin(self.h, int(budget)))
 
     def search_select(self):
-        planes = np.empty((self.G, 3, self.N, self.N), np.uint8)
-        pending = np.empty(self.G, np.int32)
+        planes = np.empty((self.G * self.L, 3, self.N, self.N), np.uint8)
+        pending = np.empty(self.G * self.L, np.int32)
         run = C.c_int()
         _chk(load().az_search_select(self.h, _ptr(planes), _ptr(pending), C.byref(run)))
         return planes, pending, run.value
@@ -190,6 +193,7 @@ class Engine:
     def search_apply(self, policy, value):
         policy = np.ascontiguousarray(policy, np.float32)
         value = np.ascontiguousarray(value, np.float32)
+        assert policy.size == self.G * self.L * self.A and value.size == self.G * self.L * 2
         _chk(load().az_search_apply(self.h, _ptr(policy), _ptr(value)))
 
     def search_result(self):

@@ -106,6 +106,8 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
     if (cfg->N < 3 || cfg->N * cfg->N > 512 - 64) return fail(AZ_E_ARG, "board side %d unsupported (3..21)", cfg->N);
     if (cfg->K < 2 || cfg->K > 8 || cfg->K > cfg->N) return fail(AZ_E_ARG, "win length %d unsupported (2..8, <= N)", cfg->K);
     if (cfg->G < 1) return fail(AZ_E_ARG, "G must be >= 1");
+    if (cfg->leaves_per_round < 0 || cfg->leaves_per_round > 64)
+        return fail(AZ_E_ARG, "leaves_per_round %d out of range (0 = 1 .. 64)", cfg->leaves_per_round);
     if (cfg->eval_mode == AZ_EVAL_TOWER) {
         if (cfg->n_Cs < 2 || cfg->n_Cs > AZ_MAX_LAYERS) return fail(AZ_E_ARG, "n_Cs %d out of range", cfg->n_Cs);
         for (int i = 1; i < cfg->n_Cs; ++i)
@@ -139,6 +141,8 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     AzTreeDev& d = c->d;
     memset(&d, 0, sizeof d);
     d.G = G; d.N = N; d.A = A; d.K = cfg->K;
+    d.L = cfg->leaves_per_round > 0 ? cfg->leaves_per_round : 1;
+    const size_t S = (size_t)G * d.L;                               // evaluation slots per round
     const int mb = cfg->max_budget > 0 ? cfg->max_budget : 800;
     d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : 4 * mb + 64;
     if (d.node_cap > 36000) return fail(AZ_E_ARG, "node_cap %d exceeds the LDS queue limit", d.node_cap);
@@ -157,9 +161,9 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         AZCHK(dalloc(c, &d.eact[a], (size_t)G * d.edge_cap, false));
     }
     DA(n_nodes, G); DA(n_edges, G); DA(root_n, G); DA(root_hist_len, G); DA(root_hist, (size_t)G * A);
-    DA(status, G); DA(sims_done, G); DA(sims_target, G); DA(pending, G); DA(path_len, G);
-    DA(path, (size_t)G * d.path_cap); DA(pend_result, 2 * (size_t)G); DA(err, G);
-    DA(leaf_planes, (size_t)G * 3 * A); DA(policy, (size_t)G * A); DA(value, 2 * (size_t)G);
+    DA(status, G); DA(sims_done, G); DA(sims_target, G); DA(pending, S); DA(path_len, S);
+    DA(path, S * d.path_cap); DA(pend_result, 2 * S); DA(err, G);
+    DA(leaf_planes, S * 3 * A); DA(policy, S * A); DA(value, 2 * S);
     DA(noise, (size_t)G * A); DA(out_policy, (size_t)G * A);
     DA(move_idx, G); DA(avg_len, G); DA(game_count, G); DA(sample_ctr, G); DA(noise_ctr, G);
     DA(row_cells, (size_t)G * A * A); DA(row_tomove, (size_t)G * A); DA(row_policy, (size_t)G * A * A);
@@ -177,7 +181,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     AZCHK(dalloc(c, &c->d_done, G)); AZCHK(dalloc(c, &c->d_illegal, 4));
     if (az_tree_configure(&d) != 0) return fail(AZ_E_HIP, "tree kernel LDS configuration failed (node_cap %d)", d.node_cap);
 
-    c->Bmax = G;
+    c->Bmax = (int)S;
     if (cfg->eval_mode == AZ_EVAL_TOWER) {
         c->C = cfg->Cs[0];
         c->C_pad = (c->C + 127) / 128 * 128;
@@ -518,7 +522,7 @@ extern "C" int az_tree_clear(az_ctx* c) {
     HIPCHK(hipMemsetAsync(c->d.n_edges, 0, sizeof(int) * G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.root_n, 0, sizeof(int) * G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.status, 0, sizeof(int) * G, c->stream));
-    HIPCHK(hipMemsetAsync(c->d.pending, 0, sizeof(int) * G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.pending, 0, sizeof(int) * G * c->d.L, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->search_active = false;
     return AZ_OK;
@@ -527,9 +531,9 @@ extern "C" int az_tree_clear(az_ctx* c) {
 // ------------------------------------------------------------------ search
 static int run_evaluator(az_ctx* c) {
     if (c->cfg.eval_mode == AZ_EVAL_TOWER)
-        return tower_run(c, c->d.leaf_planes, c->cfg.G, c->d.policy, c->d.value);
+        return tower_run(c, c->d.leaf_planes, c->cfg.G * c->d.L, c->d.policy, c->d.value);
     if (c->cfg.eval_mode == AZ_EVAL_HASH) {
-        az_launch_eval_hash(c->stream, c->d.leaf_planes, c->d.policy, c->d.value, c->cfg.G, c->A);
+        az_launch_eval_hash(c->stream, c->d.leaf_planes, c->d.policy, c->d.value, c->cfg.G * c->d.L, c->A);
         return AZ_OK;
     }
     return fail(AZ_E_STATE, "external evaluator: drive the search with az_search_select/apply");
@@ -559,12 +563,29 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "external evaluator: use az_search_select/apply");
     AZCHK(az_search_begin(c, budget));
     const int b = budget > 1 ? budget : 1;
-    // every game needs b simulations plus, for a fresh root, one root evaluation;
-    // round r applies evaluation r-1 and issues evaluation r
-    for (int r = 0; r < b + 2; ++r) {
+    // every game needs b simulations, up to L per round, plus one root evaluation for a
+    // fresh root; round r applies the evaluations of round r-1 and issues those of round r
+    const int rounds = (b + c->d.L - 1) / c->d.L + 2;
+    for (int r = 0; r < rounds; ++r) {
         az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH);
-        if (r < b + 1) AZCHK(run_evaluator(c));
+        if (r < rounds - 1) AZCHK(run_evaluator(c));
         c->rounds++;
+    }
+    // with L > 1 a round can issue fewer than L descents (two of them met at one stub):
+    // keep going until every game reports its search finished
+    std::vector<int> st(c->cfg.G);
+    for (int extra = 0; c->d.L > 1; ++extra) {
+        HIPCHK(hipMemcpyAsync(st.data(), c->d.status, sizeof(int) * c->cfg.G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        bool running = false;
+        for (int x : st) running = running || x == AZ_ST_RUN;
+        if (!running) break;
+        if (extra > b + 2) return fail(AZ_E_STATE, "search did not finish within its round bound");
+        for (int r = 0; r < 4; ++r) {
+            AZCHK(run_evaluator(c));
+            az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH);
+            c->rounds++;
+        }
     }
     HIPCHK(hipGetLastError());
     return az_search_result(c, out_policy, nullptr);
@@ -573,15 +594,18 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
 extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, int* n_running) {
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
-    const int G = c->cfg.G;
+    const int G = c->cfg.G, L = c->d.L;
     az_launch_round(c->stream, &c->d, 2, AZ_MODE_SEARCH);
     std::vector<int> st(G);
-    HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(pending, c->d.pending, sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)G * L * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pending, c->d.pending, sizeof(int) * G * L, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(st.data(), c->d.status, sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int run = 0;
-    for (int g = 0; g < G; ++g) { run += st[g] == AZ_ST_RUN; if (st[g] != AZ_ST_RUN) pending[g] = 0; }
+    for (int g = 0; g < G; ++g) {
+        run += st[g] == AZ_ST_RUN;
+        if (st[g] != AZ_ST_RUN) for (int k = 0; k < L; ++k) pending[g * L + k] = 0;
+    }
     *n_running = run;
     c->rounds++;
     return check_errors(c);
@@ -590,9 +614,9 @@ extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, in
 extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* value) {
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
-    const int G = c->cfg.G;
-    HIPCHK(hipMemcpyAsync(c->d.policy, policy, (size_t)G * c->A * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d.value, value, (size_t)G * 2 * 4, hipMemcpyHostToDevice, c->stream));
+    const size_t S = (size_t)c->cfg.G * c->d.L;
+    HIPCHK(hipMemcpyAsync(c->d.policy, policy, S * c->A * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d.value, value, S * 2 * 4, hipMemcpyHostToDevice, c->stream));
     az_launch_round(c->stream, &c->d, 1, AZ_MODE_SEARCH);
     HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
@@ -708,7 +732,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     memset(s, 0, sizeof *s);
     s->sims = (int64_t)k[0]; s->evals = (int64_t)k[1]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
     s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
-    s->max_nodes = (int32_t)k[6]; s->max_edges = (int32_t)k[7];
+    s->max_nodes = (int32_t)k[6]; s->max_edges = (int32_t)k[7]; s->sims_backed_up = (int64_t)k[8];
     s->rounds = c->rounds;
     for (int e : err) s->error_games += e != 0;
     return AZ_OK;

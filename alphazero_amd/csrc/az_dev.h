@@ -6,7 +6,9 @@
 // One child stub = one reference Node before add() (node.hpp:21-22,63-67):
 // prior p, visits n, total value v; q is v/n (recomputed, identical bits).
 // child: >=0 id of the expanded node, -1 stub, -2/-3/-4 terminal leaf whose
-// stored reward is {+1,-1} / {-1,+1} / {0,0} (Node::terminal_add, node.hpp:36-42).
+// stored reward is {+1,-1} / {-1,+1} / {0,0} (Node::terminal_add, node.hpp:36-42),
+// -5 stub whose evaluation was issued in the current round (the reference holds
+// the node's lock over that span, mcts.hpp:224-231).
 struct __attribute__((aligned(16))) AzEdge {
     float p;
     int   n;
@@ -14,6 +16,7 @@ struct __attribute__((aligned(16))) AzEdge {
     int   child;
 };
 
+enum { AZ_CHILD_WAITING = -5 };
 enum { AZ_PEND_NONE = 0, AZ_PEND_ROOT = 1, AZ_PEND_LEAF = 2, AZ_PEND_TERMINAL = 3 };
 enum { AZ_ST_IDLE = 0, AZ_ST_RUN = 1 };
 enum { AZ_MODE_SEARCH = 0, AZ_MODE_SELFPLAY = 1 };
@@ -21,6 +24,7 @@ enum { AZ_MODE_SEARCH = 0, AZ_MODE_SELFPLAY = 1 };
 // All per-game state, structure-of-arrays over the G games of one GPU.
 struct AzTreeDev {
     int G, N, A, K;
+    int L;                      // leaves (descents) per tree per round; evaluation slot = g*L + k
     int node_cap, edge_cap;     // per game, per arena
     int path_cap;               // A + 1
     float vl;
@@ -53,21 +57,21 @@ struct AzTreeDev {
     int*      status;           // [G]
     int*      sims_done;        // [G]
     int*      sims_target;      // [G]
-    int*      pending;          // [G]
-    int*      path_len;         // [G]
-    int*      path;             // [G][path_cap] edge indices root->leaf
-    float*    pend_result;      // [G][2] reward of a terminal leaf
+    int*      pending;          // [G*L]
+    int*      path_len;         // [G*L]
+    int*      path;             // [G*L][path_cap] edge indices root->leaf
+    float*    pend_result;      // [G*L][2] reward of a terminal leaf
     int*      err;              // [G] sticky error flag (arena overflow)
 
     // evaluator I/O
-    uint8_t*  leaf_planes;      // [G][3][A]
-    float*    policy;           // [G][A]
-    float*    value;            // [G][2]
+    uint8_t*  leaf_planes;      // [G*L][3][A]
+    float*    policy;           // [G*L][A]
+    float*    value;            // [G*L][2]
     float*    noise;            // [G][A]
     float*    out_policy;       // [G][A]
 
     // self-play
-    int*      move_idx;         // [G] moves played in the current game
+    int*      move_idx;         // [G] moves played in the current game, -1 during its warm-up search
     float*    avg_len;          // [G] running mean game length (generate.cpp:69)
     long long* game_count;      // [G]
     unsigned* sample_ctr;       // [G]
@@ -82,7 +86,7 @@ struct AzTreeDev {
     float*    ring_policy;      // [ring_cap][A]
     float*    ring_reward;      // [ring_cap][2]
     // counters: [0] sims [1] evals [2] moves [3] games [4] ring rows [5] dropped
-    // [6] max nodes [7] max edges
+    // [6] max nodes [7] max edges [8] simulations backed up (counted one by one)
     unsigned long long* counters;
 };
 

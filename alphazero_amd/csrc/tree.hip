@@ -1,7 +1,8 @@
 // tree.hip -- lockstep environment + MCTS kernels, one game (one tree) per
 // 64-lane wavefront, trees in flat HBM arenas.
 //
-// Restates, for nthreads = 1 and bit-exact visit statistics:
+// Restates, with bit-exact visit statistics (L = 1 leaf per tree per round is
+// the reference at nthreads = 1; L > 1 is its nthreads = L in one defined order):
 //   MCTS::__select_and_eval / __choose / Node::ucb  (mcts.hpp:211-237,350-381; node.hpp:47-55)
 //   MCTS::_eval / _append_children                   (mcts.hpp:240-321,425-455)
 //   MCTS::__backup                                   (mcts.hpp:323-346)
@@ -15,6 +16,8 @@
 
 #define AZ_WAVE 64
 #define AZ_CELLS_MAX 512
+// dynamic LDS: board bytes, then per-descent undo records (old n, old v, action), then the re-root queue
+#define AZ_SMEM_FIXED (AZ_CELLS_MAX + 3 * AZ_CELLS_MAX * 4)
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
@@ -47,8 +50,8 @@ __device__ bool az_win_check(const uint8_t* s_cells, int N, int K, int action, i
     return win;
 }
 
-__device__ void az_write_planes(const AzTreeDev& d, int g, const uint8_t* s_cells, int to_move) {
-    uint8_t* pl = d.leaf_planes + (size_t)g * 3 * d.A;
+__device__ void az_write_planes(const AzTreeDev& d, int slot, const uint8_t* s_cells, int to_move) {
+    uint8_t* pl = d.leaf_planes + (size_t)slot * 3 * d.A;
     for (int i = threadIdx.x; i < d.A; i += AZ_WAVE) {
         const uint8_t c = s_cells[i];
         pl[i] = c == 1;
@@ -199,18 +202,19 @@ __device__ int az_make_root(const AzTreeDev& d, int g, int* s_queue) {
 }
 
 // -------------------------------------------------------------- apply phase
-// Consumes the evaluation of the previous round: expand (+Dirichlet at a
+// Consumes evaluation slot k of the previous round: expand (+Dirichlet at a
 // fresh root) and back up.
-__device__ void az_apply(const AzTreeDev& d, int g, uint8_t* s_cells) {
-    const int pend = uni(d.pending[g]);
+__device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells) {
+    const int slot = g * d.L + k;
+    const int pend = uni(d.pending[slot]);
     if (pend == AZ_PEND_NONE) return;
     const int A = d.A;
     const int ar = uni(d.arena[g]);
     AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
     int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
-    const int plen = uni(d.path_len[g]);
-    const int* path = d.path + (size_t)g * d.path_cap;
+    const int plen = uni(d.path_len[slot]);
+    const int* path = d.path + (size_t)slot * d.path_cap;
     const int rt = uni(d.to_move[g]);
     const int hl = uni(d.hist_len[g]);
 
@@ -222,13 +226,13 @@ __device__ void az_apply(const AzTreeDev& d, int g, uint8_t* s_cells) {
         const int nn = uni(d.n_nodes[g]), ne0 = uni(d.n_edges[g]);
         const int legal = A - (hl + plen);
         if (nn >= d.node_cap || ne0 + legal > d.edge_cap) {
-            if (threadIdx.x == 0) { d.err[g] = 1; d.status[g] = AZ_ST_IDLE; d.pending[g] = AZ_PEND_NONE; }
+            if (threadIdx.x == 0) { d.err[g] = 1; d.status[g] = AZ_ST_IDLE; d.pending[slot] = AZ_PEND_NONE; }
             __syncthreads();
             return;
         }
         const bool is_root = pend == AZ_PEND_ROOT;
         if (is_root && d.noise_mode == 1) az_device_noise(d, g, legal);
-        const float* pol = d.policy + (size_t)g * A;
+        const float* pol = d.policy + (size_t)slot * A;
         const float* nz = d.noise + (size_t)g * A;
         int base = 0;
         for (int c = 0; c < A; c += AZ_WAVE) {                          // mcts.hpp:438-454
@@ -267,7 +271,7 @@ __device__ void az_apply(const AzTreeDev& d, int g, uint8_t* s_cells) {
             d.root_hist_len[g] = hl;
         }
     } else {                                                            // __backup, mcts.hpp:328-345
-        const float* res = pend == AZ_PEND_TERMINAL ? d.pend_result + 2 * g : d.value + 2 * g;
+        const float* res = pend == AZ_PEND_TERMINAL ? d.pend_result + 2 * slot : d.value + 2 * slot;
         const float r0 = res[0], r1 = res[1];
         const float vl = d.vl;
         for (int t = threadIdx.x; t < plen; t += AZ_WAVE) {
@@ -280,27 +284,37 @@ __device__ void az_apply(const AzTreeDev& d, int g, uint8_t* s_cells) {
         if (threadIdx.x == 0) {
             d.root_n[g] = d.root_n[g] + 1;
             d.sims_done[g] = d.sims_done[g] + 1;
+            atomicAdd(&d.counters[8], 1ull);
         }
     }
-    if (threadIdx.x == 0) d.pending[g] = AZ_PEND_NONE;
+    if (threadIdx.x == 0) d.pending[slot] = AZ_PEND_NONE;
     __syncthreads();
 }
 
 // ------------------------------------------------------------- select phase
-__device__ void az_select(const AzTreeDev& d, int g, uint8_t* s_cells) {
+// One descent into evaluation slot k.  Leaves s_cells at the root position.
+// returns 0 when the slot was filled, 1 when the round's descents must stop
+// (fresh root, error, or the descent met a stub that an earlier slot of this
+// round is already waiting on: the reference thread would block on that
+// node's lock, mcts.hpp:224 -- here the descent is undone exactly).
+__device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int* s_old) {
     const int A = d.A, N = d.N;
+    const int slot = g * d.L + k;
     const int rt = uni(d.to_move[g]);
     const int hl = uni(d.hist_len[g]);
     if (uni(d.root_hist_len[g]) < 0) {                                  // fresh root: evaluate the root board
-        az_write_planes(d, g, s_cells, rt);
-        if (threadIdx.x == 0) { d.pending[g] = AZ_PEND_ROOT; d.path_len[g] = 0; atomicAdd(&d.counters[1], 1ull); }
-        return;
+        az_write_planes(d, slot, s_cells, rt);
+        if (threadIdx.x == 0) { d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; atomicAdd(&d.counters[1], 1ull); }
+        return 1;
     }
+    int* s_old_n = s_old;
+    float* s_old_v = (float*)(s_old + AZ_CELLS_MAX);
+    int* s_act = s_old + 2 * AZ_CELLS_MAX;
     const int ar = uni(d.arena[g]);
     AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
     const int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
-    int* path = d.path + (size_t)g * d.path_cap;
+    int* path = d.path + (size_t)slot * d.path_cap;
     const float vl = d.vl;
     const float cpf = (float)d.c_puct_i;
 
@@ -328,13 +342,14 @@ __device__ void az_select(const AzTreeDev& d, int g, uint8_t* s_cells) {
         best_k = uni(best_k);
         if (best_k < 0) {                                               // mcts.hpp:374-375 would throw
             if (threadIdx.x == 0) { d.err[g] = 2; d.status[g] = AZ_ST_IDLE; }
-            return;
+            return 1;
         }
         const int ei = fe + best_k;
         AzEdge e = E[ei];
+        const int action = EA[ei];
+        if (threadIdx.x == 0) { s_old_n[depth] = e.n; s_old_v[depth] = e.v; s_act[depth] = action; }
         e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227
         e.v = e.v - vl;
-        const int action = EA[ei];
         if (threadIdx.x == 0) {
             E[ei].n = e.n; E[ei].v = e.v;
             path[depth] = ei;
@@ -346,6 +361,14 @@ __device__ void az_select(const AzTreeDev& d, int g, uint8_t* s_cells) {
         depth++;
         const int child = uni(e.child);
         if (child >= 0) { node = child; par_n = uni(e.n); continue; }
+        if (child == AZ_CHILD_WAITING) {                                // undo: n, v and the board
+            for (int t = threadIdx.x; t < depth; t += AZ_WAVE) {
+                E[path[t]].n = s_old_n[t]; E[path[t]].v = s_old_v[t];
+                s_cells[s_act[t]] = 0;
+            }
+            __syncthreads();
+            return 1;
+        }
         if (child <= -2) {                                              // stored terminal reward, mcts.hpp:232-233
             pend = AZ_PEND_TERMINAL;
             t0 = child == -2 ? 1.f : (child == -3 ? -1.f : 0.f);
@@ -362,17 +385,22 @@ __device__ void az_select(const AzTreeDev& d, int g, uint8_t* s_cells) {
             t0 = win ? (mover == 0 ? 1.f : -1.f) : 0.f;
             t1 = 0.f - t0;
         } else {
-            az_write_planes(d, g, s_cells, player);
+            az_write_planes(d, slot, s_cells, player);
+            if (threadIdx.x == 0) E[ei].child = AZ_CHILD_WAITING;
             pend = AZ_PEND_LEAF;
         }
         break;
     }
     if (threadIdx.x == 0) {
-        d.pending[g] = pend;
-        d.path_len[g] = depth;
-        if (pend == AZ_PEND_TERMINAL) { d.pend_result[2 * g] = t0; d.pend_result[2 * g + 1] = t1; }
+        d.pending[slot] = pend;
+        d.path_len[slot] = depth;
+        if (pend == AZ_PEND_TERMINAL) { d.pend_result[2 * slot] = t0; d.pend_result[2 * slot + 1] = t1; }
         else atomicAdd(&d.counters[1], 1ull);
     }
+    __syncthreads();
+    for (int t = threadIdx.x; t < depth; t += AZ_WAVE) s_cells[s_act[t]] = 0;
+    __syncthreads();
+    return 0;
 }
 
 // policy out = child n / root n (mcts.hpp:136-146)
@@ -505,9 +533,9 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells, in
         d.avg_len[g] = al + ((float)i - al) / (float)gc;
         atomicAdd(&d.counters[3], 1ull);
         d.final_reward[2 * g] = r0; d.final_reward[2 * g + 1] = 0.f - r0;
-        // env.reset(), fresh search with the warm-up doubling (generate.cpp:75-77)
-        d.hist_len[g] = 0; d.to_move[g] = 0; d.move_idx[g] = 0;
-        d.sims_done[g] = 0; d.sims_target[g] = 2 * d.budget;
+        // env.reset(), then the warm-up search (generate.cpp:75-77): move_idx -1 marks it
+        d.hist_len[g] = 0; d.to_move[g] = 0; d.move_idx[g] = -1;
+        d.sims_done[g] = 0; d.sims_target[g] = d.budget;
     }
     for (int c = threadIdx.x; c < A; c += AZ_WAVE) { d.cells[(size_t)g * A + c] = 0; s_cells[c] = 0; }
     __syncthreads();
@@ -521,39 +549,54 @@ extern "C" __global__ void __launch_bounds__(AZ_WAVE)
 az_round_kernel(AzTreeDev d, int phase_mask, int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t* s_cells = smem;
-    int* s_queue = (int*)(smem + AZ_CELLS_MAX);
+    int* s_old = (int*)(smem + AZ_CELLS_MAX);
+    int* s_queue = (int*)(smem + AZ_SMEM_FIXED);
     const int g = blockIdx.x;
     if (uni(d.status[g]) != AZ_ST_RUN) return;
     for (int c = threadIdx.x; c < d.A; c += AZ_WAVE) s_cells[c] = d.cells[(size_t)g * d.A + c];
     __syncthreads();
-    if (phase_mask & 1) az_apply(d, g, s_cells);
-    if (!(phase_mask & 2)) return;
-    if (uni(d.status[g]) != AZ_ST_RUN) return;
-    if (uni(d.pending[g]) != AZ_PEND_NONE) return;                      // select already issued
-    if (uni(d.sims_done[g]) >= uni(d.sims_target[g])) {
-        az_emit_policy(d, g);
-        if (threadIdx.x == 0) atomicAdd(&d.counters[0], (unsigned long long)d.sims_done[g]);
-        if (mode == AZ_MODE_SEARCH) {
-            if (threadIdx.x == 0) d.status[g] = AZ_ST_IDLE;
-            return;
+    if (phase_mask & 1)
+        for (int k = 0; k < d.L; ++k) {
+            az_apply(d, g, k, s_cells);
+            if (uni(d.status[g]) != AZ_ST_RUN) return;
         }
-        az_selfplay_move(d, g, s_cells, s_queue);
+    if (!(phase_mask & 2)) return;
+    if (uni(d.pending[g * d.L]) != AZ_PEND_NONE) return;                // select already issued
+    if (uni(d.sims_done[g]) >= uni(d.sims_target[g])) {
+        if (threadIdx.x == 0) atomicAdd(&d.counters[0], (unsigned long long)d.sims_done[g]);
+        if (mode == AZ_MODE_SELFPLAY && uni(d.move_idx[g]) < 0) {
+            // the warm-up search of a new game is over (generate.cpp:77); the first
+            // move's own search continues on the same root
+            __syncthreads();
+            if (threadIdx.x == 0) { d.move_idx[g] = 0; d.sims_done[g] = 0; d.sims_target[g] = d.budget; }
+            __syncthreads();
+        } else {
+            az_emit_policy(d, g);
+            if (mode == AZ_MODE_SEARCH) {
+                if (threadIdx.x == 0) d.status[g] = AZ_ST_IDLE;
+                return;
+            }
+            az_selfplay_move(d, g, s_cells, s_queue);
+        }
     }
-    az_select(d, g, s_cells);
+    // up to L descents, never more than the simulations still owed (mcts.hpp:161-174)
+    const int owed = uni(d.sims_target[g]) - uni(d.sims_done[g]);
+    for (int k = 0; k < d.L && k < owed; ++k)
+        if (az_select(d, g, k, s_cells, s_old)) break;
 }
 
 // search_probs entry: root reuse decision (mcts.hpp:121) for every game.
 extern "C" __global__ void __launch_bounds__(AZ_WAVE)
 az_begin_kernel(AzTreeDev d, int budget) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* s_queue = (int*)(smem + AZ_CELLS_MAX);
+    int* s_queue = (int*)(smem + AZ_SMEM_FIXED);
     const int g = blockIdx.x;
     const int ok = az_make_root(d, g, s_queue);
     if (threadIdx.x == 0) {
         d.sims_done[g] = 0;
-        // Q10: the loop body runs once even for budget <= 0 (mcts.hpp:161-174)
+        // the loop body runs once even for budget <= 0 (mcts.hpp:161-174)
         d.sims_target[g] = budget > 1 ? budget : 1;
-        d.pending[g] = AZ_PEND_NONE;
+        for (int k = 0; k < d.L; ++k) d.pending[g * d.L + k] = AZ_PEND_NONE;
         d.status[g] = ok ? AZ_ST_RUN : AZ_ST_IDLE;
     }
     if (!ok) {
@@ -566,10 +609,10 @@ extern "C" __global__ void az_selfplay_begin_kernel(AzTreeDev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
     d.status[g] = AZ_ST_RUN;
-    d.pending[g] = AZ_PEND_NONE;
+    for (int k = 0; k < d.L; ++k) d.pending[g * d.L + k] = AZ_PEND_NONE;
     d.sims_done[g] = 0;
-    d.sims_target[g] = 2 * d.budget;
-    d.move_idx[g] = 0;
+    d.sims_target[g] = d.budget;
+    d.move_idx[g] = -1;                                                 // warm-up search first (generate.cpp:77)
     d.avg_len[g] = 25.f;                                                // generate.cpp:69
     d.game_count[g] = 0;
     d.sample_ctr[g] = 0;
@@ -668,7 +711,7 @@ az_eval_hash_kernel(const uint8_t* planes, float* policy, float* value, int A) {
 // ------------------------------------------------------------ host launchers
 #include "az_tree.h"
 
-static inline size_t tree_smem(const AzTreeDev& d) { return AZ_CELLS_MAX + (size_t)d.node_cap * sizeof(int); }
+static inline size_t tree_smem(const AzTreeDev& d) { return AZ_SMEM_FIXED + (size_t)d.node_cap * sizeof(int); }
 
 extern "C" int az_tree_configure(const AzTreeDev* d) {
     const size_t sm = tree_smem(*d);

@@ -12,8 +12,9 @@ using Env = az::TicTacToe;
 
 int main(int argc, char** argv) {
     const int budget = argc > 1 ? atoi(argv[1]) : 50;
+    const int nthreads = argc > 2 ? atoi(argv[2]) : 1;
     { std::ofstream f("ckpt_location.txt"); f << "shim_0.pt"; }
-    az::MCTS<Env> agent(1, 16, 3, 3);
+    az::MCTS<Env> agent(nthreads, 16, 3, 3);
     Env& env = Env::get();
     agent.load();
     auto state = env.reset();

@@ -63,6 +63,8 @@ private:
         cfg.n_Cs = (int)Cs.size();
         for (size_t i = 0; i < Cs.size(); ++i) cfg.Cs[i] = Cs[i];
         cfg.vl = mcts_->vl; cfg.c_puct = mcts_->c_puct;
+        // nthreads searcher threads (mcts.hpp:54-72) become nthreads descents per round
+        cfg.leaves_per_round = mcts_->nthreads < 1 ? 1 : (mcts_->nthreads > 64 ? 64 : mcts_->nthreads);
         cfg.max_budget = mb ? atoi(mb) : 1600;
         cfg.eval_mode = AZ_EVAL_TOWER;
         cfg.noise_mode = AZ_NOISE_DEVICE;

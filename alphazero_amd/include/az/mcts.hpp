@@ -1,8 +1,10 @@
 // mcts.hpp -- MCTS<Env> (mcts.hpp:18-581) over libazhip: same constructor,
-// search_probs / load / clear, public attributes.  nthreads and batch_size are
-// accepted for source compatibility; the device search is the nthreads = 1
-// algorithm (bit-exact visit counts) and gets its parallelism from running many
-// games in lockstep (see az::SelfPlay in selfplay.hpp for the many-game driver).
+// search_probs / load / clear, public attributes.  nthreads = 1 is the reference's
+// single-thread search with bit-exact visit counts; nthreads = T > 1 runs T
+// descents per round under virtual loss in a fixed order (the reference's T
+// threads interleave nondeterministically).  batch_size is accepted for source
+// compatibility: the leaf batch is whatever one round collects.  Throughput
+// comes from many games in lockstep (az::SelfPlay in selfplay.hpp).
 #pragma once
 #include <chrono>
 #include <iostream>

@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=1,
                     help="split the GPU's games over this many engine contexts (own stream each) so that one "
                          "context's tree kernel overlaps another's tower")
+    ap.add_argument("--leaves", type=int, default=1,
+                    help="descents per tree per round (1 = the reference at nthreads=1, bit-exact; >1 = its nthreads=L "
+                         "in a fixed order, evaluation batch = games x leaves)")
     ap.add_argument("--full-games", type=float, default=0.0,
                     help="after the timed region keep playing for this many seconds and report finished games/hour")
     args = ap.parse_args()
@@ -99,7 +102,8 @@ def main():
     NC = args.contexts
     assert G % NC == 0
     engs = [capi.Engine(N, K, G // NC, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
-                        device=local_rank, game_slot_base=rank * G + i * (G // NC), precision=prec) for i in range(NC)]
+                        device=local_rank, game_slot_base=rank * G + i * (G // NC), precision=prec,
+                        leaves_per_round=args.leaves) for i in range(NC)]
     eng = engs[0]
     # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
     nw = eng.weights_size()
@@ -138,6 +142,7 @@ def main():
     run(args.warmup)
     eng.profile_enable(8)
     barrier()
+    sims0 = sum(e.stats()["sims_backed_up"] for e in engs)
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
@@ -149,6 +154,13 @@ def main():
     prof = eng.profile_read()
     sts = [e.stats() for e in engs]
     st = {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
+    sims_local = st["sims_backed_up"] - sims0              # simulations this rank backed up inside the timed region
+    if use_dist:
+        t = torch.tensor([sims_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        sims_all = int(t.item())
+    else:
+        sims_all = sims_local
     if st["error_games"]:
         raise SystemExit("tree arena overflow in %d games" % st["error_games"])
     games_info = None
@@ -172,18 +184,19 @@ def main():
     if rank == 0:
         A = N * N
         C = Cs[0]
-        sims = G * args.steps * world                     # one simulation per game per round
-        conv_flops = 2.0 * 9 * A * C * C * G               # one 3x3 conv over G boards, real cells only
+        sims = sims_all                                    # counted on the device, one per backup
+        B = G * args.leaves                                # boards per evaluation launch
+        conv_flops = 2.0 * 9 * A * C * C * B               # one 3x3 conv over B boards, real cells only
         kernel = "az_conv3x3_kernel"
         if eng.tower_is_fused():                           # stem + all 2*num_res convs in one launch
-            conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * G) / NC   # per launch of one context
+            conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * B) / NC   # per launch of one context
             kernel = "az_tower_fused_kernel"
         conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (tools/profile_bench.sh); only valid for the workload they were collected on
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj) and (N, G, budget, NC) == (15, 512, 800, 1):
+        if os.path.exists(tj) and (N, G, budget, NC, args.leaves) == (15, 512, 800, 1, 1):
             try:
                 traffic = json.load(open(tj))["kernels"][kernel]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
@@ -195,7 +208,7 @@ def main():
             "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
                                    "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
                        "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world,
-                       "contexts_per_gpu": NC},
+                       "contexts_per_gpu": NC, "leaves_per_round": args.leaves},
             "moves_per_s": sims / el / budget,
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": conv_tflops,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,

@@ -64,6 +64,11 @@ typedef struct az_config {
     int   precision;
     uint64_t seed;                /* counter-based generator seed (sampling, device noise) */
     int   game_slot_base;         /* global index of this context's game 0 (multi-GPU sharding) */
+    int   leaves_per_round;       /* L: descents per tree per round, 0 = 1.  L = 1 is the reference at
+                                     nthreads = 1; L > 1 is its nthreads = L (mcts.hpp:54-72,216-231) in one
+                                     defined order: descents in sequence under virtual loss, one batched
+                                     evaluation of the G*L slots, backups in descent order; a descent that
+                                     meets a stub already awaiting evaluation is undone and ends the round */
 } az_config;
 
 typedef struct az_stats {
@@ -77,6 +82,8 @@ typedef struct az_stats {
     int32_t max_nodes;            /* high-water mark of expanded nodes in any tree */
     int32_t max_edges;
     int32_t error_games;          /* games whose arena overflowed */
+    int32_t reserved;
+    int64_t sims_backed_up;       /* simulations backed up so far, searches in flight included */
 } az_stats;
 
 const char* az_last_error(void);
@@ -124,9 +131,10 @@ int az_set_noise(az_ctx*, const float* noise);
  * env states, including root reuse (mcts.hpp:385-421): out f32 [G,N*N]. */
 int az_search(az_ctx*, int iter_budget, float* out_policy);
 /* The same search with the evaluator outside: begin, then alternate
- * select (planes u8 [G,3,N,N]; pending i32 [G]: 0 nothing, 1 root, 2 leaf,
- * 3 terminal) and apply (policy f32 [G,N*N], value f32 [G,2]) until select
- * returns *n_running == 0, then read the result. */
+ * select (planes u8 [G*L,3,N,N]; pending i32 [G*L]: 0 nothing, 1 root, 2 leaf,
+ * 3 terminal; slot g*L+k is descent k of game g) and apply (policy f32
+ * [G*L,N*N], value f32 [G*L,2]) until select returns *n_running == 0, then
+ * read the result. */
 int az_search_begin(az_ctx*, int iter_budget);
 int az_search_select(az_ctx*, uint8_t* planes, int32_t* pending, int* n_running);
 int az_search_apply(az_ctx*, const float* policy, const float* value);

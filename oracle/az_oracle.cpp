@@ -356,6 +356,7 @@ struct azo_mcts {
     std::vector<int> root_id;       /* move history of the root (node.hpp:59) */
     std::mt19937 rng{12345u};
     long evals = 0;
+    int leaves = 1;                 /* descents per round, see round_k */
     std::vector<uint8_t> planes;
     std::vector<float> policy;
 };
@@ -469,6 +470,83 @@ static void simulate_once(azo_mcts* m) {
     node->n++;                                                      /* :345 */
 }
 
+/* ------------------------------------------------------------------------
+ * K leaves per tree per round (the reference's nthreads = K with virtual loss,
+ * mcts.hpp:54-72,216-231, whose interleaving is racy) given ONE defined order:
+ * a round performs up to K descents in sequence, each leaving its virtual loss
+ * in place, then evaluates the collected leaves, then expands and backs them
+ * up in the same order.  A descent that reaches a stub already waiting for its
+ * evaluation in this round (the reference thread would block on that node's
+ * lock, mcts.hpp:224) is undone and ends the round's descents.  K = 1 is
+ * exactly simulate_once.
+ */
+struct PendK { Node* leaf; int kind; std::vector<uint8_t> cells; int to_move; float result[2]; };
+
+static int round_k(azo_mcts* m, int K, int remaining) {
+    std::vector<PendK> pend;
+    for (int k = 0; k < K && (int)pend.size() < remaining; ++k) {
+        Node* focus = m->root.get();
+        int action = -1;
+        struct Old { Node* nd; int n; float v, q; };
+        std::vector<Old> path;
+        while (!focus->terminal && !focus->children.empty()) {
+            const size_t c = choose(focus, m->c_puct);
+            action = focus->children[c].first;
+            focus = focus->children[c].second.get();
+            path.push_back({focus, focus->n, focus->v, focus->q});
+            focus->n = (int)((float)focus->n + m->vl);
+            focus->v -= m->vl;
+            focus->q = focus->v / (float)focus->n;
+        }
+        PendK pk{focus, 0, {}, 0, {0.f, 0.f}};
+        if (focus->terminal) {
+            pk.kind = 3; pk.result[0] = focus->reward[0]; pk.result[1] = focus->reward[1];
+        } else if (focus->parent) {
+            bool collide = false;
+            for (auto& q : pend) collide = collide || (q.leaf == focus && q.kind == 2);
+            if (collide) {                       // undo this descent exactly and stop
+                for (auto it = path.rbegin(); it != path.rend(); ++it) { it->nd->n = it->n; it->nd->v = it->v; it->nd->q = it->q; }
+                break;
+            }
+            pk.cells = focus->parent->cells;
+            pk.to_move = focus->parent->player;
+            float rew[2];
+            const int done = azo_env_step(m->N, m->K, pk.cells.data(), &pk.to_move, action, rew);
+            if (done) {
+                focus->cells = pk.cells; focus->player = pk.to_move; focus->terminal = true;
+                focus->reward[0] = rew[0]; focus->reward[1] = rew[1];
+                pk.kind = 3; pk.result[0] = rew[0]; pk.result[1] = rew[1];
+            } else pk.kind = 2;
+        } else {
+            pk.kind = 3;                         // unsearchable root, see simulate_once
+        }
+        pend.push_back(pk);
+    }
+    std::vector<std::vector<float>> pols(pend.size());
+    for (size_t i = 0; i < pend.size(); ++i)
+        if (pend[i].kind == 2) {
+            evaluate(m, pend[i].cells.data(), pend[i].to_move, pend[i].result);
+            pols[i] = m->policy;
+        }
+    for (size_t i = 0; i < pend.size(); ++i) {
+        Node* leaf = pend[i].leaf;
+        if (pend[i].kind == 2) {
+            leaf->cells = pend[i].cells; leaf->player = pend[i].to_move; leaf->expanded = true;
+            append_children(m, leaf, pols[i].data(), nullptr);
+        }
+        Node* node = leaf;
+        while (node->parent) {
+            const float value = pend[i].result[node->parent->player];
+            node->n = (int)((float)node->n + (1.f - m->vl));
+            node->v += value + m->vl;
+            node->q = node->v / (float)node->n;
+            node = node->parent;
+        }
+        node->n++;
+    }
+    return (int)pend.size();
+}
+
 /* node.hpp:83-102 + mcts.hpp:385-421 */
 static void make_root(azo_mcts* m, const std::vector<int>& id, const uint8_t* cells, int to_move,
                       const float* noise) {
@@ -527,13 +605,30 @@ extern "C" int azo_mcts_search(azo_mcts* m, const int32_t* history, int hist_len
     }
     if (over) return -1;
     make_root(m, id, cells.data(), to_move, noise);
-    int count = 0;
-    do { simulate_once(m); } while (!(++count > budget - 1));      /* :161-174, nthreads=1 */
+    if (m->leaves > 1) {
+        const int target = budget > 1 ? budget : 1;
+        int done = 0;
+        while (done < target) done += round_k(m, m->leaves, target - done);
+    } else {
+        int count = 0;
+        do { simulate_once(m); } while (!(++count > budget - 1));  /* :161-174, nthreads=1 */
+    }
     for (int i = 0; i < A; ++i) out_policy[i] = 0.f;               /* :124 */
     const Node* r = m->root.get();
     for (const auto& ch : r->children)                              /* :136-146 */
         out_policy[ch.first] = (float)ch.second->n / (float)r->n;
     return 0;
+}
+
+extern "C" void azo_mcts_set_leaves(azo_mcts* m, int K) { m->leaves = K > 1 ? K : 1; }
+
+extern "C" int azo_mcts_search_k(azo_mcts* m, const int32_t* history, int hist_len, int budget, int K,
+                                 const float* noise, float* out_policy) {
+    const int keep = m->leaves;
+    azo_mcts_set_leaves(m, K);
+    const int rc = azo_mcts_search(m, history, hist_len, budget, noise, out_policy);
+    m->leaves = keep;
+    return rc;
 }
 
 extern "C" int azo_mcts_dump(const azo_mcts* m, int cap, int32_t* parent, int32_t* action,

@@ -78,6 +78,14 @@ void azo_mcts_destroy(azo_mcts*);
  * returns 0, or -1 on an illegal history. */
 int  azo_mcts_search(azo_mcts*, const int32_t* history, int hist_len, int budget,
                      const float* noise, float* out_policy);
+/* The same search with up to K descents per round (virtual loss between them,
+ * evaluations batched, backups in descent order): the defined-order form of the
+ * reference's nthreads = K (mcts.hpp:54-72,216-231).  K = 1 == azo_mcts_search. */
+int  azo_mcts_search_k(azo_mcts*, const int32_t* history, int hist_len, int budget, int K,
+                       const float* noise, float* out_policy);
+/* Make every later search of this instance (azo_selfplay_game included) use K
+ * descents per round. */
+void azo_mcts_set_leaves(azo_mcts*, int K);
 void azo_mcts_clear(azo_mcts*);                 /* mcts.hpp:462-465 */
 void azo_mcts_seed(azo_mcts*, uint64_t seed);
 int  azo_mcts_root_n(const azo_mcts*);

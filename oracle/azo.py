@@ -169,6 +169,18 @@ class MCTS:
             raise ValueError("illegal history")
         return out
 
+    def search_k(self, history, budget, K, noise=None):
+        hist = np.ascontiguousarray(history, np.int32)
+        out = np.zeros(self.N * self.N, np.float32)
+        nz = None if noise is None else _p(np.ascontiguousarray(noise, np.float32), C.c_float)
+        rc = lib().azo_mcts_search_k(self.h, _p(hist, C.c_int32), len(hist), int(budget), int(K), nz, _p(out, C.c_float))
+        if rc != 0:
+            raise ValueError("illegal history")
+        return out
+
+    def set_leaves(self, K):
+        lib().azo_mcts_set_leaves(self.h, int(K))
+
     def clear(self):
         lib().azo_mcts_clear(self.h)
 

@@ -16,11 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "alphazero_amd", "host")
 
 
-def test_mcts_pvnetwork_shims_play_a_game():
+@pytest.mark.parametrize("nthreads", [1, 4])
+def test_mcts_pvnetwork_shims_play_a_game(nthreads):
+    """MCTS<Env>(nthreads, ...) through the shim: nthreads searcher threads become
+    nthreads descents per round; the visit-count invariants hold either way."""
     exe = os.path.join(HOST, "shim_check")
     assert os.path.exists(exe), "build alphazero_amd/host first (__graft_entry__.build())"
     with tempfile.TemporaryDirectory() as d:
-        out = subprocess.run([exe, "50"], cwd=d, capture_output=True, text=True, timeout=120)
+        out = subprocess.run([exe, "50", str(nthreads)], cwd=d, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "shim ok" in out.stdout
         lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("move ")]

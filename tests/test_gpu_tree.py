@@ -150,3 +150,94 @@ def test_selfplay_matches_oracle_games():
     got = {(cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm))}
     missing = [w for w in want if w not in got]
     assert not missing, "%d of %d oracle rows not produced by the device" % (len(missing), len(want))
+
+
+@pytest.mark.parametrize("L", [2, 4, 8])
+@pytest.mark.parametrize("N,K,budget,moves", [(3, 3, 64, 9), (9, 5, 203, 5)])
+def test_multi_leaf_search_matches_oracle(N, K, budget, moves, L):
+    """L descents per tree per round (the reference's nthreads = L in a fixed
+    order): trees and policies equal the oracle's restatement of the same
+    order, across root reuse, with budgets that L does not divide."""
+    G = 5
+    A = N * N
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget, leaves_per_round=L)
+    noise = np.stack([azo.dirichlet(300 + g, A)[0] for g in range(G)])
+    eng.set_noise(noise)
+    eng.env_reset()
+    orc = [azo.MCTS(N, K, 3.0, 3.0, "hash") for _ in range(G)]
+    hist = [[] for _ in range(G)]
+    alive = [True] * G
+    for mv in range(moves):
+        out = eng.search(budget)
+        acts = np.full(G, -1, np.int32)
+        for g in range(G):
+            if not alive[g]:
+                continue
+            ref = orc[g].search_k(hist[g], budget, L, noise[g])
+            assert np.array_equal(out[g], ref), (mv, g)
+            assert eng.tree_canonical(g) == azo.canonical_tree(orc[g].dump())
+            order = np.argsort(-ref, kind="stable")
+            acts[g] = order[min(g, 2)] if ref[order[min(g, 2)]] > 0 else order[0]
+        _, done = eng.env_step(acts)
+        for g in range(G):
+            if alive[g]:
+                hist[g].append(int(acts[g]))
+                alive[g] = not bool(done[g])
+
+
+def test_multi_leaf_external_evaluator():
+    """The select/apply protocol with L = 3 slots per game: the caller answers
+    slot g*L+k; result equals the fused search."""
+    N, K, G, L, budget = 7, 5, 3, 3, 100
+    A = N * N
+    noise = np.stack([azo.dirichlet(900 + g, A)[0] for g in range(G)])
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_EXTERNAL, max_budget=budget, leaves_per_round=L)
+    eng.set_noise(noise)
+    eng.env_reset()
+    eng.search_begin(budget)
+    batch_sizes = []
+    while True:
+        planes, pending, running = eng.search_select()
+        if running == 0:
+            break
+        pol = np.zeros((G * L, A), np.float32)
+        val = np.zeros((G * L, 2), np.float32)
+        for s in range(G * L):
+            if pending[s] in (1, 2):
+                pol[s], val[s] = azo.eval_hash(N, planes[s])
+        batch_sizes.append(int(np.isin(pending, (1, 2)).sum()))
+        eng.search_apply(pol, val)
+    out, root_n = eng.search_result()
+    assert max(batch_sizes) > G                       # more than one leaf per game in a round
+    for g in range(G):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        assert np.array_equal(out[g], m.search_k([], budget, L, noise[g]))
+        assert root_n[g] == m.root_n()
+        assert eng.tree_canonical(g) == azo.canonical_tree(m.dump())
+
+
+def test_multi_leaf_selfplay_matches_oracle_games():
+    N, K, budget, G, L = 5, 4, 50, 6, 4
+    A = N * N
+    seed = 91
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget, seed=seed, leaves_per_round=L)
+    noise = np.stack([azo.dirichlet(700 + g, A)[0] for g in range(G)])
+    eng.set_noise(noise)
+    eng.selfplay_begin(budget)
+    eng.selfplay_run((2 * budget + 1 + (A - 1) * budget) * 2 + 8)    # generous: collisions only shorten rounds' work
+    cells, tm, pol, rew = eng.replay_drain()
+    st = eng.stats()
+    assert st["games"] >= 2 * G and st["error_games"] == 0
+    want = []
+    for g in range(G):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        m.set_leaves(L)
+        avg, gc, sc = 25.0, 0, 0
+        for _ in range(2):
+            r = m.selfplay_game(budget, seed, g, noise[g], avg, gc, sc)
+            avg, gc, sc = r["avg_len"], r["game_count"], r["sample_counter"]
+            for i in range(r["n_moves"]):
+                want.append((r["cells"][i].tobytes(), int(r["to_move"][i]), r["policy"][i].tobytes(), r["reward"].tobytes()))
+    got = {(cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm))}
+    missing = [w for w in want if w not in got]
+    assert not missing, "%d of %d oracle rows not produced by the device" % (len(missing), len(want))

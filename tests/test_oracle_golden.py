@@ -46,3 +46,28 @@ def test_tower_restatement_matches_reference(path):
     # fp32 vs fp32 with a different summation order: tolerance 2e-5 abs
     assert np.abs(pol - z["policy"][:B]).max() < 2e-5
     assert np.abs(val - z["value"][:B]).max() < 2e-5
+
+
+def test_multi_leaf_order_reduces_to_single_thread_search():
+    """The K-descents-per-round order is the single-thread search at K = 1 and
+    keeps the reference's invariants (root n = 1 + simulations, policy sums to
+    (n-1)/n) for K > 1, including budgets K does not divide and root reuse."""
+    N, K = 7, 5
+    A = N * N
+    noise = azo.dirichlet(3, A)[0]
+    a, b = azo.MCTS(N, K, 3.0, 3.0, "hash"), azo.MCTS(N, K, 3.0, 3.0, "hash")
+    hist = []
+    for mv in range(3):
+        p1, p2 = a.search(hist, 150, noise), b.search_k(hist, 150, 1, noise)
+        assert np.array_equal(p1, p2)
+        assert azo.canonical_tree(a.dump()) == azo.canonical_tree(b.dump())
+        hist.append(int(np.argmax(p1)))
+    for leaves in (2, 5, 16):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        p = m.search_k([], 203, leaves, noise)
+        assert m.root_n() == 204
+        assert abs(float(p.sum()) - 203.0 / 204.0) < 1e-6
+        d = m.dump()
+        assert (d["n"] >= 0).all()                 # every virtual loss was paid back
+        p = m.search_k([int(np.argmax(p))], 100, leaves, noise)
+        assert abs(float(p.sum()) - (m.root_n() - 1) / m.root_n()) < 1e-6
