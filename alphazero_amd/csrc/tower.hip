@@ -49,6 +49,14 @@ template <> struct Prec<0> {
         const f2 f = {fmaxf(a, 0.f), fmaxf(b, 0.f)};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
     }
+    // largest storable activation; pack2 takes values already clamped to [0, cap]
+    static __device__ __forceinline__ float cap() { return __builtin_inff(); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 f = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
+    }
 };
 template <> struct Prec<1> {
     typedef f16x8 vec;
@@ -66,6 +74,13 @@ template <> struct Prec<1> {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 f = {__builtin_amdgcn_fmed3f(a, 0.f, 65504.f), __builtin_amdgcn_fmed3f(b, 0.f, 65504.f)};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
+    }
+    static __device__ __forceinline__ float cap() { return 65504.f; }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 f = {a, b};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
     }
 };
@@ -284,6 +299,173 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 //   heads : policy softmax and value MLP straight from the LDS-resident activations
 #define I_STRIDE 80             // 32 k * 2 B + 16 B pad
 
+// Optional phase timing of the fused kernel (build with -DAZ_TOWER_TIMING): wave 0 of
+// two workgroups stamps the shader clock at phase boundaries; read with az_tower_timing_read.
+#ifdef AZ_TOWER_TIMING
+__device__ unsigned long long az_tower_ts[2][64];
+#define TSTAMP(slot_) do { if (ts_blk >= 0 && tid == 0) az_tower_ts[ts_blk][slot_] = __builtin_readcyclecounter(); } while (0)
+extern "C" int az_tower_timing_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(az_tower_ts), sizeof(unsigned long long) * 128);
+}
+#else
+#define TSTAMP(slot_) do {} while (0)
+#endif
+
+// Accumulator tile of one wave in the MFMA C/D layout: 128 channels x 64 positions.
+// T[i][j][4q+c] = channel 32i + 8q + 4h + c, position 32j + l31 of the wave's 64 rows.
+typedef f32x16 AccTile[4][2];
+
+// T = bias[channel], broadcast over positions (the convolution then accumulates on top).
+__device__ __forceinline__ void fused_bias_init(AccTile& T, const float* bptr, int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *(const float4*)(bptr + 32 * i + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                T[i][j][4 * q + 0] = bv.x; T[i][j][4 * q + 1] = bv.y;
+                T[i][j][4 * q + 2] = bv.z; T[i][j][4 * q + 3] = bv.w;
+            }
+        }
+}
+
+// ReLU, the 16-bit format's saturation and the padding mask in ONE v_med3_f32 per value:
+// cap is Prec::cap() for a real board cell and 0 for a padding row of the raster (whose
+// LDS copy must stay zero: neighbours read it as the convolution's zero padding).
+__device__ __forceinline__ float relu_cap(float x, float cap) { return __builtin_amdgcn_fmed3f(x, 0.f, cap); }
+
+// First convolution of a ResBlock (network.hpp:33): h = relu(Y) goes to LDS as 16-bit
+// activations, and Y restarts from the bias of the next block's first convolution.
+template <int PR>
+__device__ __forceinline__ void fused_epi_hidden(AccTile& Y, const float* next_bias, unsigned char* row0,
+                                                 float cap0, float cap1, int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *(const float4*)(next_bias + 32 * i + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float cap = j ? cap1 : cap0;
+                uint2 o;
+                o.x = Prec<PR>::pack2(relu_cap(Y[i][j][4 * q + 0], cap), relu_cap(Y[i][j][4 * q + 1], cap));
+                o.y = Prec<PR>::pack2(relu_cap(Y[i][j][4 * q + 2], cap), relu_cap(Y[i][j][4 * q + 3], cap));
+                *(uint2*)(row0 + j * 32 * A_STRIDE + (32 * i + 8 * q) * 2) = o;
+                Y[i][j][4 * q + 0] = bv.x; Y[i][j][4 * q + 1] = bv.y;
+                Y[i][j][4 * q + 2] = bv.z; Y[i][j][4 * q + 3] = bv.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // 32 values at a time: short live ranges, no spills
+    }
+}
+
+// Stem and second convolution of a ResBlock (network.hpp:34-37): X already holds
+// residual + bias + convolution (it was accumulated in place), so x = relu(X) is both
+// the new fp32 residual and, rounded to 16 bits, the next layer's input in LDS; X then
+// takes the bias of the next block's second convolution on top of the residual.  The
+// residual of a padding row is held at zero too (it only ever feeds itself).
+template <int PR>
+__device__ __forceinline__ void fused_epi_residual(AccTile& X, const float* next_bias, unsigned char* row0,
+                                                   float cap0, float cap1, int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *(const float4*)(next_bias + 32 * i + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float cap = j ? cap1 : cap0;
+                const float r0 = relu_cap(X[i][j][4 * q + 0], cap), r1 = relu_cap(X[i][j][4 * q + 1], cap);
+                const float r2 = relu_cap(X[i][j][4 * q + 2], cap), r3 = relu_cap(X[i][j][4 * q + 3], cap);
+                uint2 o;
+                o.x = Prec<PR>::pack2(r0, r1);
+                o.y = Prec<PR>::pack2(r2, r3);
+                *(uint2*)(row0 + j * 32 * A_STRIDE + (32 * i + 8 * q) * 2) = o;
+                X[i][j][4 * q + 0] = r0 + bv.x; X[i][j][4 * q + 1] = r1 + bv.y;
+                X[i][j][4 * q + 2] = r2 + bv.z; X[i][j][4 * q + 3] = r3 + bv.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One 3x3 convolution (nine taps) accumulated onto `acc`.  Weight chunk g + tap sits in
+// buffer (g + tap) & 1 when the tap starts; chunk g + tap + 1 streams in behind it.
+// One chunk = one tap = [n=128][k=128] 16-bit = 32 KB, copied global -> LDS by the DMA path
+// (global_load_lds, 16 B per lane, no staging registers).  The LDS image is lane-linear,
+// so the bank-conflict fix is an XOR swizzle applied to the SOURCE address and again on
+// the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
+template <int PR>
+__device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
+                                                const unsigned char* wbytes, unsigned st_off, unsigned char* st_dst,
+                                                int posrow0, int W, int h, int l31) {
+    const int swz = l31 & 15;
+#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_global_load_lds( \
+        (gl_void*)(wbytes + ((size_t)(g_) * (128 * 128 * 2) + (p_) * 4096) + st_off), \
+        (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, 0, 0)
+    // fragments double-buffered in registers: the reads of the next k-step are issued
+    // ahead of the MFMAs of the current one (one wave per SIMD, so nothing else hides
+    // the LDS latency), and the pipeline runs across tap boundaries: the barrier that
+    // hands over the weight buffers sits before the LAST k-step of a tap, whose MFMAs
+    // then cover the first fragment reads of the next tap.
+    typename Prec<PR>::vec fx[2][2], fw[2][4];
+    const unsigned char* bA = sA + (posrow0 - W - 1) * A_STRIDE + h * 16;          // tap 0: (-1,-1)
+    const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
+    for (int tap = 0; tap < 9; ++tap, ++g) {
+        // the chunk after this one; after the very last chunk the DMA re-fetches it into the idle
+        // buffer (nobody reads that): no branch in the k-step code
+        const int gn = g + 1 < total ? g + 1 : g;
+        // the tap after this one (the last tap of a layer re-reads itself: harmless, unused)
+        const int tn = tap < 8 ? tap + 1 : 8;
+        const unsigned char* nA = sA + (posrow0 + (tn / 3 - 1) * W + (tn % 3 - 1)) * A_STRIDE + h * 16;
+        const unsigned char* nB = sB + ((g + 1) & 1) * W_BUF_BYTES + l31 * 256;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            // two 4 KB pieces of the next tap in each of the first four k-steps: the last piece
+            // still has three k-steps (~750 cycles) to land before the barrier
+            if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
+            if (ks < 7) {
+                const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + wo);
+            } else {
+                // every wave holds its last fragments of this tap in registers and the
+                // next tap's weights have landed (vmcnt(0)): hand the buffers over
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(nA + j * 32 * A_STRIDE);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(nB + i * 32 * 256 + ((h ^ swz) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = Prec<PR>::mfma(fw[ks & 1][i], fx[ks & 1][j], acc[i][j]);
+            // one fragment read per MFMA gap, activations first: they feed the next k-step's
+            // first MFMAs, the last weight fragment is not needed until its seventh
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);           // the DMA pieces
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);                           // k-steps do not mix
+        }
+        bA = nA; bB = nB;
+    }
+#undef STAGE_W
+}
+
 template <int PR>
 __global__ void __launch_bounds__(256)
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
@@ -307,6 +489,11 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int b0 = blockIdx.x * bpt;                         // first board of the tile
     const int nb_here = min(bpt, B - b0);
     const int rows_here = nb_here * P;                       // tile rows that belong to boards
+#ifdef AZ_TOWER_TIMING
+    const int ts_blk = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : -1);
+    if (ts_blk >= 0 && tid == 0) az_tower_ts[ts_blk][63] = __builtin_amdgcn_s_memrealtime();
+#endif
+    TSTAMP(0);
 
     // zero the activation tile (guards and idle rows stay zero for the whole kernel)
     for (int i = tid; i < a_rows * (A_STRIDE / 16); i += 256) *(uint4*)(sA + i * 16) = make_uint4(0, 0, 0, 0);
@@ -347,22 +534,16 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     }
     __syncthreads();
 
-    f32x16 acc[4][2];
-    float res[4][2][16];                                     // fp32 residual stream, C/D layout
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    AccTile X, Y;        // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
+    fused_bias_init(X, sBias, h);                            // stem bias
 
     // which of this lane's two positions are real board cells
-    bool real[2];
+    float keepcap[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = 64 * wv + 32 * j + l31;
         const int p = r % P;
-        real[j] = r < rows_here && (p / W) < N && (p % W) < N;
+        keepcap[j] = (r < rows_here && (p / W) < N && (p % W) < N) ? Prec<PR>::cap() : 0.f;
     }
 
     // stem: 2 k-steps of 16 over the im2col tile
@@ -377,119 +558,46 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = Prec<PR>::mfma(wa[i], xb[j], acc[i][j]);
+                X[i][j] = Prec<PR>::mfma(wa[i], xb[j], X[i][j]);
     }
-    // epilogue shared by the stem and every conv.  keep: the result also becomes the
-    // fp32 residual (stem output and every conv2 output); skip: add the residual first.
-    const unsigned keepmask[2] = {real[0] ? 0xFFFFFFFFu : 0u, real[1] ? 0xFFFFFFFFu : 0u};
-    auto epilogue = [&](const float* bptr, bool skip, bool keep) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned char* rowp = sA + (size_t)(Gd + 64 * wv + 32 * j + l31) * A_STRIDE + 8 * h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bv = *(const float4*)(bptr + 32 * i + 8 * q + 4 * h);
-                    float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
-                    float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
-                    if (skip) {
-                        v0 += res[i][j][4 * q + 0]; v1 += res[i][j][4 * q + 1];
-                        v2 += res[i][j][4 * q + 2]; v3 += res[i][j][4 * q + 3];
-                    }
-                    if (keep) {              // residual of padding rows only ever feeds padding rows
-                        res[i][j][4 * q + 0] = fmaxf(v0, 0.f); res[i][j][4 * q + 1] = fmaxf(v1, 0.f);
-                        res[i][j][4 * q + 2] = fmaxf(v2, 0.f); res[i][j][4 * q + 3] = fmaxf(v3, 0.f);
-                    }
-                    uint2 o;                 // the LDS copy is what neighbours read: padding rows must be 0
-                    o.x = Prec<PR>::pack2_relu(v0, v1) & keepmask[j];
-                    o.y = Prec<PR>::pack2_relu(v2, v3) & keepmask[j];
-                    *(uint2*)(rowp + (32 * i + 8 * q) * 2) = o;
-                    acc[i][j][4 * q + 0] = 0.f; acc[i][j][4 * q + 1] = 0.f;
-                    acc[i][j][4 * q + 2] = 0.f; acc[i][j][4 * q + 3] = 0.f;
-                }
-        }
-    };
     __syncthreads();                                         // every wave is done with sI / sW
-    epilogue(sBias, false, true);
+    // bias table: [0] stem, [1 + L] convolution L.  Block b = convolutions 2b (onto Y) and 2b+1 (onto X).
+    unsigned char* const row0 = sA + (size_t)(Gd + 64 * wv + l31) * A_STRIDE + 8 * h;
+    fused_epi_residual<PR>(X, sBias + 2 * 128, row0, keepcap[0], keepcap[1], h);
+    fused_bias_init(Y, sBias + 1 * 128, h);
 
-    // Weight stream: one chunk = one 3x3 tap = [n=128][k=128] bf16 = 32 KB,
-    // copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no
-    // staging registers), two buffers.  The LDS image is lane-linear, so the
-    // bank-conflict fix is an XOR swizzle applied to the SOURCE address and again
-    // on the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
+    // weight stream set-up (see fused_conv_taps): piece p (0..7) of a chunk is 256 lanes x 16 B;
+    // lane's piece index q = p*256 + tid -> LDS row q>>4 = p*16 + (tid>>4), physical piece tid&15,
+    // logical piece ^ (row&15)
     const int total = n_layers * 9;
-    // piece p (0..7) of chunk g: 256 lanes x 16 B; lane's piece index q = p*256 + tid
-    // -> LDS row q>>4 = p*16 + (tid>>4), physical piece tid&15, logical piece ^ (row&15)
     const int st_row = tid >> 4;
-    const int st_src = st_row * 128 + (((tid & 15) ^ (st_row & 15)) << 3);       // elements; row&15 == st_row
-    unsigned char* const st_dst = sB + (tid & ~63) * 16;                        // wave-uniform
-#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_global_load_lds( \
-        (gl_void*)(wpk + (size_t)(g_) * (128 * 128) + (p_) * (16 * 128) + st_src), \
-        (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, 0, 0)
+    // per-lane byte offset inside a piece (32-bit, added to a scalar base by the load itself)
+    const unsigned st_off = (unsigned)(st_row * 128 + (((tid & 15) ^ (st_row & 15)) << 3)) * 2u;   // row&15 == st_row
+    // the LDS side is wave-uniform: keep it in scalar registers so that setting M0 costs no VALU work
+    unsigned char* const st_dst = sB + __builtin_amdgcn_readfirstlane(wv) * 1024;
+    const unsigned char* const wbytes = (const unsigned char*)wpk;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) STAGE_W(0, 0, p);
+    for (int p = 0; p < 8; ++p)
+        __builtin_amdgcn_global_load_lds((gl_void*)(wbytes + p * 4096 + st_off), (lds_void*)(st_dst + p * 4096), 16, 0, 0);
     __syncthreads();
+    TSTAMP(1);
 
     const int posrow0 = Gd + 64 * wv + l31;
-    const int swz = l31 & 15;
-    int g = 0;
-    for (int L = 0; L < n_layers; ++L) {
-        for (int tap = 0; tap < 9; ++tap, ++g) {
-            const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
-            const bool more = g + 1 < total;
-            const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + h * 16;
-            const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
-            // fragments double-buffered in registers: the reads of k-step ks+1 are
-            // issued ahead of the MFMAs of k-step ks (one wave per SIMD, so nothing
-            // else hides the LDS latency)
-            typename Prec<PR>::vec fx[2][2], fw[2][4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                // two 4 KB pieces of the next tap in each of the first four k-steps: the DMA
-                // issue cost hides under MFMAs and the last piece still has four k-steps
-                // (~1000 cycles) to land before the barrier
-                if (more && ks < 4) { STAGE_W(g + 1, (g + 1) & 1, 2 * ks); STAGE_W(g + 1, (g + 1) & 1, 2 * ks + 1); }
-                if (ks < 7) {
-                    const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + wo);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = Prec<PR>::mfma(fw[ks & 1][i], fx[ks & 1][j], acc[i][j]);
-                if (ks < 7) {
-                    // the six fragment reads of k-step ks+1 go out in the first three MFMA
-                    // gaps, leaving five MFMAs (160 cycles) to cover the LDS latency
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // 2 DS reads
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // a DMA piece
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // a DMA piece
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);       // 3 MFMAs
-                }
-            }
-            __syncthreads();                                 // next tap landed (vmcnt(0)), this one fully read
-        }
-        // all waves have finished reading this layer's input: overwrite it in place
-        if (L & 1) epilogue(sBias + (L + 1) * 128, true, true);
-        else epilogue(sBias + (L + 1) * 128, false, false);
+    const int n_blocks = n_layers >> 1;
+    for (int b = 0; b < n_blocks; ++b) {
+        const int nb1 = min(3 + 2 * b, n_layers), nb2 = min(4 + 2 * b, n_layers);     // next block's biases
+        fused_conv_taps<PR>(Y, 18 * b, total, sA, sB, wbytes, st_off, st_dst, posrow0, W, h, l31);
+        // (the barrier before the last k-step: all waves have finished reading this layer's input)
+        TSTAMP(2 + 4 * b);
+        fused_epi_hidden<PR>(Y, sBias + nb1 * 128, row0, keepcap[0], keepcap[1], h);
         __syncthreads();
+        TSTAMP(3 + 4 * b);
+        fused_conv_taps<PR>(X, 18 * b + 9, total, sA, sB, wbytes, st_off, st_dst, posrow0, W, h, l31);
+        TSTAMP(4 + 4 * b);
+        fused_epi_residual<PR>(X, sBias + nb2 * 128, row0, keepcap[0], keepcap[1], h);
+        __syncthreads();
+        TSTAMP(5 + 4 * b);
     }
-#undef STAGE_W
     // ---- heads, on the activations still resident in LDS --------------------
     // PolicyHead (network.hpp:51-60): 1x1 conv -> softmax over each board's N*N cells.
     // ValueHead (network.hpp:75-83): 1x1 conv -> BN(1) -> ReLU -> fc1 -> ReLU -> fc2 -> softmax*2-1.
@@ -589,6 +697,10 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             __syncthreads();
         }
     }
+    TSTAMP(60);
+#ifdef AZ_TOWER_TIMING
+    if (ts_blk >= 0 && tid == 0) az_tower_ts[ts_blk][62] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------- heads
