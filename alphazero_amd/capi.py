@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazhip.so")
+LIB_PATH = os.environ.get("AZ_HIP_LIB") or os.path.join(_HERE, "libazhip.so")   # AZ_HIP_LIB: A/B another build
 
 AZ_EVAL_TOWER, AZ_EVAL_HASH, AZ_EVAL_EXTERNAL = 0, 1, 2
 AZ_NOISE_EXPLICIT, AZ_NOISE_DEVICE = 0, 1

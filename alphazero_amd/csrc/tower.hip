@@ -398,12 +398,15 @@ __device__ __forceinline__ void fused_epi_residual(AccTile& X, const float* next
 // the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
 template <int PR>
 __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
-                                                const unsigned char* wbytes, unsigned st_off, unsigned char* st_dst,
+                                                __amdgpu_buffer_rsrc_t wrsrc, unsigned st_off, unsigned char* st_dst,
                                                 int posrow0, int W, int h, int l31) {
     const int swz = l31 & 15;
-#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_global_load_lds( \
-        (gl_void*)(wbytes + ((size_t)(g_) * (128 * 128 * 2) + (p_) * 4096) + st_off), \
-        (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, 0, 0)
+    // buffer-addressed form of the LDS DMA: scalar resource + scalar chunk offset + per-lane
+    // 32-bit offset (no 64-bit vector address arithmetic), and the compiler keeps counted
+    // s_waitcnt lgkmcnt(N) for the fragment reads while pieces are in flight (with the
+    // global_load_lds form it drains the LDS queue to zero before every dependent MFMA)
+#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+        wrsrc, (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, st_off, (g_) * (128 * 128 * 2) + (p_) * 4096, 0, 0)
     // fragments double-buffered in registers: the reads of the next k-step are issued
     // ahead of the MFMAs of the current one (one wave per SIMD, so nothing else hides
     // the LDS latency), and the pipeline runs across tap boundaries: the barrier that
@@ -417,6 +420,9 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
     for (int tap = 0; tap < 9; ++tap, ++g) {
+#ifdef AZ_TOWER_TIMING
+        if (g >= 72 && g < 81 && blockIdx.x == 0 && threadIdx.x == 0) az_tower_ts[0][45 + tap] = __builtin_readcyclecounter();
+#endif
         // the chunk after this one; after the very last chunk the DMA re-fetches it into the idle
         // buffer (nobody reads that): no branch in the k-step code
         const int gn = g + 1 < total ? g + 1 : g;
@@ -426,40 +432,34 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
         const unsigned char* nB = sB + ((g + 1) & 1) * W_BUF_BYTES + l31 * 256;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            // two 4 KB pieces of the next tap in each of the first four k-steps: the last piece
-            // still has three k-steps (~750 cycles) to land before the barrier
-            if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
-            if (ks < 7) {
-                const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + wo);
-            } else {
-                // every wave holds its last fragments of this tap in registers and the
-                // next tap's weights have landed (vmcnt(0)): hand the buffers over
+            // One k-step = 8 MFMAs in a fixed order with, between them, the six fragment reads of
+            // the NEXT k-step (activations first, then weights in the order the MFMAs will want
+            // them: every read has a full k-step, ~256 cycles, to return) and, in the first four
+            // k-steps, two 4 KB pieces of the next tap's weights (the last piece still has three
+            // k-steps, ~750 cycles, to land before the hand-over barrier).
+            const int c = ks & 1, n = c ^ 1;
+            const unsigned char* rA = ks < 7 ? bA + (ks + 1) * 32 : nA;
+            const unsigned char* rB = ks < 7 ? bB + ((((ks + 1) * 2 + h) ^ swz) << 4) : nB + ((h ^ swz) << 4);
+            if (ks == 7) {
+                // every wave holds its last fragments of this tap in registers and the next
+                // tap's weights have landed (vmcnt(0)): hand the buffers over
                 __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(nA + j * 32 * A_STRIDE);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(nB + i * 32 * 256 + ((h ^ swz) << 4));
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = Prec<PR>::mfma(fw[ks & 1][i], fx[ks & 1][j], acc[i][j]);
-            // one fragment read per MFMA gap, activations first: they feed the next k-step's
-            // first MFMAs, the last weight fragment is not needed until its seventh
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);           // the DMA pieces
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);                           // k-steps do not mix
+#define MF_(i_, j_) acc[i_][j_] = Prec<PR>::mfma(fw[c][i_], fx[c][j_], acc[i_][j_])
+#define FENCE_ __builtin_amdgcn_sched_barrier(0)
+            MF_(0, 0); fx[n][0] = *(const typename Prec<PR>::vec*)(rA); FENCE_;
+            MF_(0, 1); fx[n][1] = *(const typename Prec<PR>::vec*)(rA + 32 * A_STRIDE); FENCE_;
+            MF_(1, 0); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); FENCE_;
+            MF_(1, 1); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 256); FENCE_;
+            MF_(2, 0); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 256); FENCE_;
+            MF_(2, 1); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 256); FENCE_;
+            MF_(3, 0);
+            if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
+            FENCE_;
+            MF_(3, 1); FENCE_;
+#undef MF_
+#undef FENCE_
         }
         bA = nA; bB = nB;
     }
@@ -504,6 +504,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     for (int i = tid; i < 128 * 4; i += 256)
         *(uint4*)(sW + (i >> 2) * I_STRIDE + (i & 3) * 16) = *(const uint4*)(stem_w + (size_t)i * 8);
     __syncthreads();
+    TSTAMP(40);
     {   // im2col row of tile position `tid`: k = ci*9 + ky*3 + kx, bf16(u8) is exact
         unsigned short v[32];
 #pragma unroll
@@ -533,6 +534,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         }
     }
     __syncthreads();
+    TSTAMP(41);
 
     AccTile X, Y;        // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
     fused_bias_init(X, sBias, h);                            // stem bias
@@ -561,6 +563,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                 X[i][j] = Prec<PR>::mfma(wa[i], xb[j], X[i][j]);
     }
     __syncthreads();                                         // every wave is done with sI / sW
+    TSTAMP(42);
     // bias table: [0] stem, [1 + L] convolution L.  Block b = convolutions 2b (onto Y) and 2b+1 (onto X).
     unsigned char* const row0 = sA + (size_t)(Gd + 64 * wv + l31) * A_STRIDE + 8 * h;
     fused_epi_residual<PR>(X, sBias + 2 * 128, row0, keepcap[0], keepcap[1], h);
@@ -575,10 +578,11 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const unsigned st_off = (unsigned)(st_row * 128 + (((tid & 15) ^ (st_row & 15)) << 3)) * 2u;   // row&15 == st_row
     // the LDS side is wave-uniform: keep it in scalar registers so that setting M0 costs no VALU work
     unsigned char* const st_dst = sB + __builtin_amdgcn_readfirstlane(wv) * 1024;
-    const unsigned char* const wbytes = (const unsigned char*)wpk;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, total * (128 * 128 * 2), 0x00020000);
 #pragma unroll
     for (int p = 0; p < 8; ++p)
-        __builtin_amdgcn_global_load_lds((gl_void*)(wbytes + p * 4096 + st_off), (lds_void*)(st_dst + p * 4096), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st_dst + p * 4096), 16, st_off, p * 4096, 0, 0);
     __syncthreads();
     TSTAMP(1);
 
@@ -586,13 +590,13 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int n_blocks = n_layers >> 1;
     for (int b = 0; b < n_blocks; ++b) {
         const int nb1 = min(3 + 2 * b, n_layers), nb2 = min(4 + 2 * b, n_layers);     // next block's biases
-        fused_conv_taps<PR>(Y, 18 * b, total, sA, sB, wbytes, st_off, st_dst, posrow0, W, h, l31);
+        fused_conv_taps<PR>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         // (the barrier before the last k-step: all waves have finished reading this layer's input)
         TSTAMP(2 + 4 * b);
         fused_epi_hidden<PR>(Y, sBias + nb1 * 128, row0, keepcap[0], keepcap[1], h);
         __syncthreads();
         TSTAMP(3 + 4 * b);
-        fused_conv_taps<PR>(X, 18 * b + 9, total, sA, sB, wbytes, st_off, st_dst, posrow0, W, h, l31);
+        fused_conv_taps<PR>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         TSTAMP(4 + 4 * b);
         fused_epi_residual<PR>(X, sBias + nb2 * 128, row0, keepcap[0], keepcap[1], h);
         __syncthreads();
@@ -635,6 +639,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                 }
             }
         }
+        TSTAMP(43);
         s_logit[r] = cell ? sp + bp : -3.4e38f;
         s_u[r] = cell ? fmaxf(sv + bvv, 0.f) : 0.f;
         for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
@@ -666,6 +671,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             for (int k = 0; k < P; ++k) sum += s_logit[base + k];
             if (cell) policy[(size_t)(b0 + r / P) * A + py * N + px] = e / sum;
         }
+        TSTAMP(44);
         for (int bi = 0; bi < nb_here; ++bi) {       // value head, one board at a time
             const int o = tid & 63, part = tid >> 6;
             float acc1 = 0.f;

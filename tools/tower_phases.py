@@ -37,6 +37,11 @@ def main():
               "epilogues %d (%.0f per layer), heads %d" %
               ("first" if blk == 0 else "last", total, real_us, total / (real_us * 1e3), t[1] - t[0], taps, taps / L,
                epi, epi / L, t[60] - t[3 + 2 * (L - 1)]))
+        print("   setup: zero+loads %d, im2col %d, stem mfma %d, stem epilogue+first weights %d; heads: 1x1 convs %d, softmax %d, value mlp %d" %
+              (t[40] - t[0], t[41] - t[40], t[42] - t[41], t[1] - t[42], t[43] - t[3 + 2 * (L - 1)], t[44] - t[43], t[60] - t[44]))
+        if blk == 0:
+            print("   layer 8 tap starts (delta):", [int(t[46 + k] - t[45 + k]) for k in range(8)], "last tap:", int(t[2 + 2 * 8] - t[53]),
+                  "prologue:", int(t[45] - t[3 + 2 * 7]))
         print("   per-layer taps:", [int(t[2 + 2 * l] - (t[1] if l == 0 else t[3 + 2 * (l - 1)])) for l in range(L)])
         print("   per-layer epi :", [int(t[3 + 2 * l] - t[2 + 2 * l]) for l in range(L)])
 
