@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from alphazero_amd import capi, synth  # noqa: E402
 
-capi.LIB_PATH = os.path.join(ROOT, "tools", "dbg", os.environ.get("AZ_TIMING_LIB", "libazhip_timing.so"))
+capi.LIB_PATH = os.path.join(ROOT, "tools", "dbg", os.environ.get("AZ_TIMING_LIB", "libazhip_timing.so"))   # tools/dbg is git-ignored: build it first (see docstring)
 
 
 def main():
