@@ -48,7 +48,7 @@ struct az_ctx {
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
     float* head_p = nullptr;
-    float* head_pt = nullptr;                             // fused path: fc1 weights transposed [A][64]
+    float* head_pt = nullptr;                             // fused path: 1x1 weights as {policy, value} pairs, fc1 transposed [A][64]
     size_t conv_layer_elems = 0;
     uint8_t* tower_in = nullptr;                          // staging for az_tower_forward [Bmax][3][A]
     float *tower_pol = nullptr, *tower_val = nullptr;
@@ -347,7 +347,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     HIPCHK(hipMemcpy(c->head_p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
     if (c->fused) {
         std::vector<float> ht((size_t)258 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
-        for (int ch = 0; ch < C; ++ch) { ht[ch] = hp[ch]; ht[128 + ch] = hp[Cp + ch]; }
+        for (int ch = 0; ch < C; ++ch) { ht[2 * ch] = hp[ch]; ht[2 * ch + 1] = hp[Cp + ch]; }   // {policy, value} pairs
         ht[256] = hp[2 * Cp]; ht[257] = hp[2 * Cp + 1];
         for (int o = 0; o < 64; ++o)
             for (int a2 = 0; a2 < A; ++a2) ht[258 + (size_t)a2 * 64 + o] = fc1w[(size_t)o * A + a2];

@@ -495,14 +495,32 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 #endif
     TSTAMP(0);
 
-    // zero the activation tile (guards and idle rows stay zero for the whole kernel)
-    for (int i = tid; i < a_rows * (A_STRIDE / 16); i += 256) *(uint4*)(sA + i * 16) = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < nb_here * 3 * A; i += 256) sP[i] = planes[(size_t)b0 * 3 * A + i];
+    // Set-up: every global load is issued before the first LDS store that depends on one, so
+    // the latencies overlap.  Only the guard rows need zeroing: the stem epilogue writes all
+    // 256 tile rows (padding and idle rows as zeros).
+    const int np = nb_here * 3 * A;                          // <= 768 plane bytes per tile
+    uint8_t pl[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) pl[t] = tid + 256 * t < np ? planes[(size_t)b0 * 3 * A + tid + 256 * t] : (uint8_t)0;
+    uint4 sw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) sw[t] = *(const uint4*)(stem_w + (size_t)(tid + 256 * t) * 8);
     // all biases into LDS once: the per-layer epilogue then never waits on HBM/L2
-    for (int i = tid; i < 128; i += 256) sBias[i] = stem_b[i];
-    for (int i = tid; i < n_layers * 128; i += 256) sBias[128 + i] = bias[i];
-    for (int i = tid; i < 128 * 4; i += 256)
-        *(uint4*)(sW + (i >> 2) * I_STRIDE + (i & 3) * 16) = *(const uint4*)(stem_w + (size_t)i * 8);
+    const int nb4 = (n_layers + 1) * 32;                     // float4s: stem bias, then every conv's
+#pragma unroll 3
+    for (int i = tid; i < nb4; i += 256)
+        ((float4*)sBias)[i] = i < 32 ? ((const float4*)stem_b)[i] : ((const float4*)bias)[i - 32];
+    for (int i = tid; i < 2 * Gd * (A_STRIDE / 16); i += 256) {
+        const int r = i / (A_STRIDE / 16), c = i % (A_STRIDE / 16);
+        *(uint4*)(sA + (size_t)(r < Gd ? r : r + TILE_M) * A_STRIDE + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) if (tid + 256 * t < np) sP[tid + 256 * t] = pl[t];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = tid + 256 * t;
+        *(uint4*)(sW + (i >> 2) * I_STRIDE + (i & 3) * 16) = sw[t];
+    }
     __syncthreads();
     TSTAMP(40);
     {   // im2col row of tile position `tid`: k = ci*9 + ky*3 + kx, bf16(u8) is exact
@@ -605,7 +623,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     // ---- heads, on the activations still resident in LDS --------------------
     // PolicyHead (network.hpp:51-60): 1x1 conv -> softmax over each board's N*N cells.
     // ValueHead (network.hpp:75-83): 1x1 conv -> BN(1) -> ReLU -> fc1 -> ReLU -> fc2 -> softmax*2-1.
-    // hp (fp32): wp[128], wv[128] (BN folded), bp, bv, fc1 weights TRANSPOSED [A][64]
+    // hp (fp32): {wp[c], wv[c]} pairs for c < 128 (BN folded), bp, bv, fc1 weights TRANSPOSED [A][64]
     // (so the 64 outputs of one cell are one coalesced 256-byte read), fc1b[64], fc2w[2][64], fc2b[2].
     {
         float* s_logit = (float*)sB;                 // [256] the weight buffers are free now
@@ -613,8 +631,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         float* s_part = s_u + 256;                   // [4][64]
         float* s_red = s_part + 256;                 // [8]
         int* s_map = (int*)(s_red + 8);              // [A] cell -> padded-raster row
-        const float* wp = hp;
-        const float* wvv = hp + 128;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2* wpv = (const f32x2*)hp;         // {policy weight, value weight} of channel c: one packed FMA feeds both heads
         const float bp = hp[256], bvv = hp[257];
         const float* fc1t = hp + 258;
         const float* fc1b = fc1t + 64 * A;
@@ -623,7 +641,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         const int r = tid;
         const int pp = r % P, py = pp / W, px = pp % W;
         const bool cell = r < rows_here && py < N && px < N;
-        float sp = 0.f, sv = 0.f;
+        f32x2 spv = {0.f, 0.f};
         if (cell) {
             const unsigned char* row = sA + (size_t)(Gd + r) * A_STRIDE;
 #pragma unroll 4
@@ -634,14 +652,14 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                 for (int t = 0; t < 4; ++t) {
                     const float lo = Prec<PR>::from16((unsigned short)(u[t] & 0xFFFFu));
                     const float hi = Prec<PR>::from16((unsigned short)(u[t] >> 16));
-                    sp += lo * wp[c + 2 * t] + hi * wp[c + 2 * t + 1];
-                    sv += lo * wvv[c + 2 * t] + hi * wvv[c + 2 * t + 1];
+                    spv += (f32x2){lo, lo} * wpv[c + 2 * t];
+                    spv += (f32x2){hi, hi} * wpv[c + 2 * t + 1];
                 }
             }
         }
         TSTAMP(43);
-        s_logit[r] = cell ? sp + bp : -3.4e38f;
-        s_u[r] = cell ? fmaxf(sv + bvv, 0.f) : 0.f;
+        s_logit[r] = cell ? spv.x + bp : -3.4e38f;
+        s_u[r] = cell ? fmaxf(spv.y + bvv, 0.f) : 0.f;
         for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
         __syncthreads();
         // softmax over each board's cells, reductions in a fixed order (deterministic bits)
@@ -676,7 +694,25 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             const int o = tid & 63, part = tid >> 6;
             float acc1 = 0.f;
             int a = part;
-            for (; a + 28 < A; a += 32) {            // 8 independent loads in flight per lane
+            for (; a + 124 < A; a += 128) {          // 32 independent L2 loads in flight per lane
+                float wv32[32], uv32[32];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) wv32[t] = fc1t[(a + 4 * t) * 64 + o];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) uv32[t] = s_u[bi * P + s_map[a + 4 * t]];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) acc1 += wv32[t] * uv32[t];
+            }
+            for (; a + 60 < A; a += 64) {
+                float wv16[16], uv16[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) wv16[t] = fc1t[(a + 4 * t) * 64 + o];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) uv16[t] = s_u[bi * P + s_map[a + 4 * t]];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc1 += wv16[t] * uv16[t];
+            }
+            for (; a + 28 < A; a += 32) {
                 float wv8[8], uv8[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) wv8[t] = fc1t[(a + 4 * t) * 64 + o];
