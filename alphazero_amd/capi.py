@@ -23,7 +23,7 @@ EXPORTS = [
     "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
-    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step",
+    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
 ]
 
 
@@ -264,6 +264,9 @@ class Engine:
 
     def tower_is_fused(self):
         return bool(load().az_tower_is_fused(self.h))
+
+    def selfplay_batch(self):
+        return int(load().az_selfplay_batch(self.h))
 
     def profile_enable(self, every):
         _chk(load().az_profile_enable(self.h, int(every)))

@@ -65,16 +65,20 @@ struct az_ctx {
     std::vector<std::pair<size_t, int>> prof_spans;       // (first event index, kind 0 conv / 1 tree)
 };
 
-static bool prof_begin(az_ctx* c, int kind, bool sampled) {
+static bool prof_begin(az_ctx* c, int kind, bool sampled, hipStream_t s) {
     if (!sampled || c->prof_used + 2 > c->prof_pool.size()) return false;
     c->prof_spans.push_back({c->prof_used, kind});
-    (void)hipEventRecord(c->prof_pool[c->prof_used], c->stream);
+    (void)hipEventRecord(c->prof_pool[c->prof_used], s);
     return true;
 }
-static void prof_end(az_ctx* c, bool on) {
+static void prof_end(az_ctx* c, bool on, hipStream_t s) {
     if (!on) return;
-    (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream);
+    (void)hipEventRecord(c->prof_pool[c->prof_used + 1], s);
     c->prof_used += 2;
+}
+static int sync_all(az_ctx* c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AZ_OK;
 }
 
 template <class T>
@@ -145,7 +149,6 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     const size_t S = (size_t)G * d.L;                               // evaluation slots per round
     const int mb = cfg->max_budget > 0 ? cfg->max_budget : 800;
     d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : 4 * mb + 64;
-    if (d.node_cap > 36000) return fail(AZ_E_ARG, "node_cap %d exceeds the LDS queue limit", d.node_cap);
     d.edge_cap = (int)std::min<long long>((long long)d.node_cap * A, 2000000000ll);
     d.path_cap = A + 1;
     d.vl = cfg->vl; d.c_puct_i = (int)cfg->c_puct;
@@ -161,6 +164,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         AZCHK(dalloc(c, &d.eact[a], (size_t)G * d.edge_cap, false));
     }
     DA(n_nodes, G); DA(n_edges, G); DA(root_n, G); DA(root_hist_len, G); DA(root_hist, (size_t)G * A);
+    AZCHK(dalloc(c, &d.queue, (size_t)G * d.node_cap, false));
     DA(status, G); DA(sims_done, G); DA(sims_target, G); DA(pending, S); DA(path_len, S);
     DA(path, S * d.path_cap); DA(pend_result, 2 * S); DA(err, G);
     DA(leaf_planes, S * 3 * A); DA(policy, S * A); DA(value, 2 * S);
@@ -220,7 +224,8 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
 }
 
 extern "C" int az_tower_is_fused(const az_ctx* c) { return c->fused ? 1 : 0; }
-extern "C" int az_sync(az_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return AZ_OK; }
+extern "C" int az_selfplay_batch(const az_ctx* c) { return c->cfg.G * c->d.L; }
+extern "C" int az_sync(az_ctx* c) { return sync_all(c); }
 extern "C" void* az_stream(az_ctx* c) { return (void*)c->stream; }
 
 // ----------------------------------------------------------------- weights
@@ -375,10 +380,10 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
     if (c->fused) {
-        const bool on = prof_begin(c, 0, sampled);
+        const bool on = prof_begin(c, 0, sampled, c->stream);
         az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
                               c->head_pt, pol_dev, val_dev, B, N, Gd, 2 * c->num_res);
-        prof_end(c, on);
+        prof_end(c, on, c->stream);
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
@@ -386,12 +391,12 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
-        bool on = prof_begin(c, 0, sampled);
+        bool on = prof_begin(c, 0, sampled, c->stream);
         az_launch_conv3x3(c->stream, c->prec, c->actX, c->actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
-        prof_end(c, on);
-        on = prof_begin(c, 0, sampled);
+        prof_end(c, on, c->stream);
+        on = prof_begin(c, 0, sampled, c->stream);
         az_launch_conv3x3(c->stream, c->prec, c->actH, c->actX, c->actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
-        prof_end(c, on);
+        prof_end(c, on, c->stream);
     }
     az_launch_heads(c->stream, c->prec, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
     HIPCHK(hipGetLastError());
@@ -529,15 +534,19 @@ extern "C" int az_tree_clear(az_ctx* c) {
 }
 
 // ------------------------------------------------------------------ search
-static int run_evaluator(az_ctx* c) {
+// evaluate the leaves of games [g0, g0 + count) (slots g*L .. ) on the context's main stream
+static int run_evaluator(az_ctx* c, int g0, int count) {
+    const size_t s0 = (size_t)g0 * c->d.L;
+    const int B = count * c->d.L;
     if (c->cfg.eval_mode == AZ_EVAL_TOWER)
-        return tower_run(c, c->d.leaf_planes, c->cfg.G * c->d.L, c->d.policy, c->d.value);
+        return tower_run(c, c->d.leaf_planes + s0 * 3 * c->A, B, c->d.policy + s0 * c->A, c->d.value + s0 * 2);
     if (c->cfg.eval_mode == AZ_EVAL_HASH) {
-        az_launch_eval_hash(c->stream, c->d.leaf_planes, c->d.policy, c->d.value, c->cfg.G * c->d.L, c->A);
+        az_launch_eval_hash(c->stream, c->d.leaf_planes + s0 * 3 * c->A, c->d.policy + s0 * c->A, c->d.value + s0 * 2, B, c->A);
         return AZ_OK;
     }
     return fail(AZ_E_STATE, "external evaluator: drive the search with az_search_select/apply");
 }
+static int run_evaluator(az_ctx* c) { return run_evaluator(c, 0, c->cfg.G); }
 
 static int check_errors(az_ctx* c) {
     std::vector<int> err(c->cfg.G);
@@ -567,7 +576,7 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
     // fresh root; round r applies the evaluations of round r-1 and issues those of round r
     const int rounds = (b + c->d.L - 1) / c->d.L + 2;
     for (int r = 0; r < rounds; ++r) {
-        az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH);
+        az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH, 0, c->cfg.G);
         if (r < rounds - 1) AZCHK(run_evaluator(c));
         c->rounds++;
     }
@@ -583,7 +592,7 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
         if (extra > b + 2) return fail(AZ_E_STATE, "search did not finish within its round bound");
         for (int r = 0; r < 4; ++r) {
             AZCHK(run_evaluator(c));
-            az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH);
+            az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH, 0, c->cfg.G);
             c->rounds++;
         }
     }
@@ -595,7 +604,7 @@ extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, in
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, L = c->d.L;
-    az_launch_round(c->stream, &c->d, 2, AZ_MODE_SEARCH);
+    az_launch_round(c->stream, &c->d, 2, AZ_MODE_SEARCH, 0, c->cfg.G);
     std::vector<int> st(G);
     HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)G * L * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(pending, c->d.pending, sizeof(int) * G * L, hipMemcpyDeviceToHost, c->stream));
@@ -617,7 +626,7 @@ extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* valu
     const size_t S = (size_t)c->cfg.G * c->d.L;
     HIPCHK(hipMemcpyAsync(c->d.policy, policy, S * c->A * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d.value, value, S * 2 * 4, hipMemcpyHostToDevice, c->stream));
-    az_launch_round(c->stream, &c->d, 1, AZ_MODE_SEARCH);
+    az_launch_round(c->stream, &c->d, 1, AZ_MODE_SEARCH, 0, c->cfg.G);
     HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
 }
@@ -677,7 +686,7 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     HIPCHK(hipMemsetAsync(c->d.err, 0, sizeof(int) * c->cfg.G, c->stream));
     az_launch_selfplay_begin(c->stream, &c->d);
     // issue the first evaluation so that every later round is evaluate -> tree
-    az_launch_round(c->stream, &c->d, 2, AZ_MODE_SELFPLAY);
+    az_launch_round(c->stream, &c->d, 2, AZ_MODE_SELFPLAY, 0, c->cfg.G);
     HIPCHK(hipGetLastError());
     c->search_active = false;
     return AZ_OK;
@@ -688,9 +697,9 @@ extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
     HIPCHK(hipSetDevice(c->cfg.device));
     for (int r = 0; r < rounds; ++r) {
         AZCHK(run_evaluator(c));
-        const bool on = prof_begin(c, 1, c->prof_every > 0 && (c->rounds % c->prof_every) == 0);
-        az_launch_round(c->stream, &c->d, 3, AZ_MODE_SELFPLAY);
-        prof_end(c, on);
+        const bool on = prof_begin(c, 1, c->prof_every > 0 && (c->rounds % c->prof_every) == 0, c->stream);
+        az_launch_round(c->stream, &c->d, 3, AZ_MODE_SELFPLAY, 0, c->cfg.G);
+        prof_end(c, on, c->stream);
         c->rounds++;
     }
     HIPCHK(hipGetLastError());

@@ -52,6 +52,7 @@ struct AzTreeDev {
     int*      root_n;           // [G]
     int*      root_hist_len;    // [G] -1 = no tree
     uint16_t* root_hist;        // [G][A]
+    int*      queue;            // [G][node_cap] BFS queue of the re-root copy
 
     // search state
     int*      status;           // [G]

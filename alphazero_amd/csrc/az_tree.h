@@ -4,7 +4,8 @@
 
 extern "C" {
 int  az_tree_configure(const AzTreeDev* d);
-void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode);
+// one lockstep round over games [g0, g0 + count)
+void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode, int g0, int count);
 void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget);
 void az_launch_selfplay_begin(hipStream_t s, const AzTreeDev* d);
 void az_launch_env_step(hipStream_t s, const AzTreeDev* d, const int* actions, float* reward,

@@ -466,8 +466,13 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
 #undef STAGE_W
 }
 
+// Register budget: 400 of the SIMD's 512 per lane (amdgpu_num_vgpr counts half of the unified
+// file) -- nothing spills, and a 64-register wave of the tree kernel can live on every SIMD
+// beside the tower's wave (its block needs 6.5 KB of LDS, the tower leaves 8.8 KB), so when a
+// process runs two contexts on two streams one context's tree round executes under the
+// other's tower instead of waiting for it.
 template <int PR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224)))
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
                       const float* __restrict__ bias, const float* __restrict__ hp,

@@ -16,7 +16,8 @@
 
 #define AZ_WAVE 64
 #define AZ_CELLS_MAX 512
-// dynamic LDS: board bytes, then per-descent undo records (old n, old v, action), then the re-root queue
+// LDS of a tree block: board bytes, then per-descent undo records (old n, old v, action): 6.5 KB,
+// small enough to sit on a CU beside a resident tower workgroup
 #define AZ_SMEM_FIXED (AZ_CELLS_MAX + 3 * AZ_CELLS_MAX * 4)
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -108,7 +109,7 @@ __device__ void az_device_noise(const AzTreeDev& d, int g, int count) {
 // Copies the subtree under `target` into the other arena in BFS order so the
 // new root is node 0 (the reference just drops the shared_ptr to the old
 // root, mcts.hpp:417-420).  Returns false if the arena bookkeeping is corrupt.
-__device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n, int* s_queue) {
+__device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n) {
     const int ar = uni(d.arena[g]);
     const AzEdge* E0 = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* A0 = d.eact[ar] + (size_t)g * d.edge_cap;
@@ -116,11 +117,20 @@ __device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n, i
     AzEdge* E1 = d.edges[ar ^ 1] + (size_t)g * d.edge_cap;
     uint16_t* A1 = d.eact[ar ^ 1] + (size_t)g * d.edge_cap;
     int2* N1 = d.nodes[ar ^ 1] + (size_t)g * d.node_cap;
-    if (threadIdx.x == 0) s_queue[0] = target;
+    // BFS queue of old node ids in HBM (the block's LDS stays small enough to share a CU
+    // with a resident tower workgroup); the wave reads it 64 entries at a time
+    int* queue = d.queue + (size_t)g * d.node_cap;
+    if (threadIdx.x == 0) queue[0] = target;
     __syncthreads();
     int new_count = 1, new_edges = 0;
+    int win_base = 0, win_end = 0, win_val = 0;                         // queue[win_base + lane] for entries < win_end
     for (int i = 0; i < new_count; ++i) {
-        const int old = uni(s_queue[i]);
+        if (i >= win_end) {
+            win_base = i;
+            win_end = min(i + AZ_WAVE, new_count);
+            win_val = win_base + (int)threadIdx.x < win_end ? queue[win_base + threadIdx.x] : 0;
+        }
+        const int old = __shfl(win_val, i - win_base, AZ_WAVE);
         const int2 nd = N0[old];
         const int fe = uni(nd.x), ne = uni(nd.y);
         if (threadIdx.x == 0) N1[i] = make_int2(new_edges, ne);
@@ -134,7 +144,7 @@ __device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n, i
             const unsigned long long m = __ballot(has);
             if (has) {
                 const int idx = new_count + __popcll(m & lanemask_lt());
-                s_queue[idx] = e.child;
+                queue[idx] = e.child;
                 e.child = idx;
             }
             if (valid) { E1[new_edges + k] = e; A1[new_edges + k] = act; }
@@ -162,7 +172,7 @@ __device__ void az_drop_tree(const AzTreeDev& d, int g) {
 
 // find() + the reuse rule of __make_root for the current env history.
 // returns 1 if the position is searchable, 0 if the root is a finished game.
-__device__ int az_make_root(const AzTreeDev& d, int g, int* s_queue) {
+__device__ int az_make_root(const AzTreeDev& d, int g) {
     const int hl = uni(d.hist_len[g]);
     const int rhl = uni(d.root_hist_len[g]);
     if (uni(d.game_over[g])) { az_drop_tree(d, g); return 0; }
@@ -197,14 +207,14 @@ __device__ int az_make_root(const AzTreeDev& d, int g, int* s_queue) {
         node = child;
         tn = uni(e.n);
     }
-    az_reroot(d, g, node, tn, s_queue);
+    az_reroot(d, g, node, tn);
     return 1;
 }
 
 // -------------------------------------------------------------- apply phase
 // Consumes evaluation slot k of the previous round: expand (+Dirichlet at a
 // fresh root) and back up.
-__device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells) {
+__device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int* s_act) {
     const int slot = g * d.L + k;
     const int pend = uni(d.pending[slot]);
     if (pend == AZ_PEND_NONE) return;
@@ -219,9 +229,13 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells) {
     const int hl = uni(d.hist_len[g]);
 
     if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
-        // the leaf position = root position + the moves along the path
-        if (threadIdx.x == 0)
-            for (int t = 0; t < plen; ++t) s_cells[EA[path[t]]] = (uint8_t)((rt ^ (t & 1)) + 1);
+        // the leaf position = root position + the moves along the path (one lane per ply:
+        // the two dependent loads of every ply are in flight together)
+        for (int t = threadIdx.x; t < plen; t += AZ_WAVE) {
+            const int act = EA[path[t]];
+            s_act[t] = act;
+            s_cells[act] = (uint8_t)((rt ^ (t & 1)) + 1);
+        }
         __syncthreads();
         const int nn = uni(d.n_nodes[g]), ne0 = uni(d.n_edges[g]);
         const int legal = A - (hl + plen);
@@ -260,8 +274,7 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells) {
         }
         __syncthreads();
         // restore the root position in LDS
-        if (threadIdx.x == 0)
-            for (int t = 0; t < plen; ++t) s_cells[EA[path[t]]] = 0;
+        for (int t = threadIdx.x; t < plen; t += AZ_WAVE) s_cells[s_act[t]] = 0;
         __syncthreads();
     }
     if (pend == AZ_PEND_ROOT) {                                         // mcts.hpp:412-413
@@ -326,27 +339,36 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         const double s = sqrt((double)(par_n - 1));                     // node.hpp:54 sqrt(int) -> double
         float best_val = -100.f;                                        // mcts.hpp:355
         int best_k = -1;
+        AzEdge be = {0.f, 0, 0.f, -1};                                  // this lane's best candidate, whole
+        int bact = 0;
         for (int k = threadIdx.x; k < ne; k += AZ_WAVE) {
             const AzEdge e = E[fe + k];
+            const int act = EA[fe + k];
             const float q = e.n != 0 ? __fdiv_rn(e.v, (float)e.n) : 0.f;
             const float cp = cpf * e.p;                                 // int * float -> float
             const double u = (double)cp * s / (double)(1 + e.n);
             const float val = (float)((double)q + u);
-            if (val > best_val) { best_val = val; best_k = k; }
+            if (val > best_val) { best_val = val; best_k = k; be = e; bact = act; }
         }
+        int win_k = best_k;
         for (int o = 32; o > 0; o >>= 1) {                              // first maximum in child order
             const float ov = __shfl_xor(best_val, o, AZ_WAVE);
-            const int ok = __shfl_xor(best_k, o, AZ_WAVE);
-            if (ok >= 0 && (best_k < 0 || ov > best_val || (ov == best_val && ok < best_k))) { best_val = ov; best_k = ok; }
+            const int ok = __shfl_xor(win_k, o, AZ_WAVE);
+            if (ok >= 0 && (win_k < 0 || ov > best_val || (ov == best_val && ok < win_k))) { best_val = ov; win_k = ok; }
         }
-        best_k = uni(best_k);
-        if (best_k < 0) {                                               // mcts.hpp:374-375 would throw
+        win_k = uni(win_k);
+        if (win_k < 0) {                                                // mcts.hpp:374-375 would throw
             if (threadIdx.x == 0) { d.err[g] = 2; d.status[g] = AZ_ST_IDLE; }
             return 1;
         }
-        const int ei = fe + best_k;
-        AzEdge e = E[ei];
-        const int action = EA[ei];
+        // the winner's edge comes from the lane that scanned it, not from memory again: lane
+        // k % 64 scanned child k, and the wave's first maximum is also that lane's own first maximum
+        const int owner = win_k & (AZ_WAVE - 1);
+        const int ei = fe + win_k;
+        AzEdge e;
+        e.p = __shfl(be.p, owner, AZ_WAVE); e.n = __shfl(be.n, owner, AZ_WAVE);
+        e.v = __shfl(be.v, owner, AZ_WAVE); e.child = __shfl(be.child, owner, AZ_WAVE);
+        const int action = __shfl(bact, owner, AZ_WAVE);
         if (threadIdx.x == 0) { s_old_n[depth] = e.n; s_old_v[depth] = e.v; s_act[depth] = action; }
         e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227
         e.v = e.v - vl;
@@ -422,7 +444,7 @@ __device__ void az_emit_policy(const AzTreeDev& d, int g) {
 
 // -------------------------------------------------------- self-play control
 // generate.cpp:84-118 for one slot after its search completed.
-__device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells, int* s_queue) {
+__device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells) {
     const int A = d.A, N = d.N;
     const int i = uni(d.move_idx[g]) + 1;                               // generate.cpp:82
     const int rt = uni(d.to_move[g]);
@@ -496,7 +518,7 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells, in
     if (!done) {
         if (threadIdx.x == 0) { d.move_idx[g] = i; d.sims_done[g] = 0; d.sims_target[g] = d.budget; }
         __syncthreads();
-        if (child >= 0) az_reroot(d, g, child, child_n, s_queue); else az_drop_tree(d, g);
+        if (child >= 0) az_reroot(d, g, child, child_n); else az_drop_tree(d, g);
         return;
     }
     // game over: buffer.send_reward(reward); agent.clear(); stats (generate.cpp:110-118)
@@ -546,18 +568,17 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells, in
 // One lockstep round.  phase_mask bit0: apply the pending evaluation,
 // bit1: advance (finish search / play move / select the next leaf).
 extern "C" __global__ void __launch_bounds__(AZ_WAVE)
-az_round_kernel(AzTreeDev d, int phase_mask, int mode) {
+az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t* s_cells = smem;
     int* s_old = (int*)(smem + AZ_CELLS_MAX);
-    int* s_queue = (int*)(smem + AZ_SMEM_FIXED);
-    const int g = blockIdx.x;
+    const int g = g0 + blockIdx.x;                                      // a launch covers games [g0, g0 + gridDim.x)
     if (uni(d.status[g]) != AZ_ST_RUN) return;
     for (int c = threadIdx.x; c < d.A; c += AZ_WAVE) s_cells[c] = d.cells[(size_t)g * d.A + c];
     __syncthreads();
     if (phase_mask & 1)
         for (int k = 0; k < d.L; ++k) {
-            az_apply(d, g, k, s_cells);
+            az_apply(d, g, k, s_cells, s_old + 2 * AZ_CELLS_MAX);
             if (uni(d.status[g]) != AZ_ST_RUN) return;
         }
     if (!(phase_mask & 2)) return;
@@ -576,7 +597,7 @@ az_round_kernel(AzTreeDev d, int phase_mask, int mode) {
                 if (threadIdx.x == 0) d.status[g] = AZ_ST_IDLE;
                 return;
             }
-            az_selfplay_move(d, g, s_cells, s_queue);
+            az_selfplay_move(d, g, s_cells);
         }
     }
     // up to L descents, never more than the simulations still owed (mcts.hpp:161-174)
@@ -588,10 +609,8 @@ az_round_kernel(AzTreeDev d, int phase_mask, int mode) {
 // search_probs entry: root reuse decision (mcts.hpp:121) for every game.
 extern "C" __global__ void __launch_bounds__(AZ_WAVE)
 az_begin_kernel(AzTreeDev d, int budget) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* s_queue = (int*)(smem + AZ_SMEM_FIXED);
     const int g = blockIdx.x;
-    const int ok = az_make_root(d, g, s_queue);
+    const int ok = az_make_root(d, g);
     if (threadIdx.x == 0) {
         d.sims_done[g] = 0;
         // the loop body runs once even for budget <= 0 (mcts.hpp:161-174)
@@ -711,18 +730,11 @@ az_eval_hash_kernel(const uint8_t* planes, float* policy, float* value, int A) {
 // ------------------------------------------------------------ host launchers
 #include "az_tree.h"
 
-static inline size_t tree_smem(const AzTreeDev& d) { return AZ_SMEM_FIXED + (size_t)d.node_cap * sizeof(int); }
+static inline size_t tree_smem(const AzTreeDev&) { return AZ_SMEM_FIXED; }
 
-extern "C" int az_tree_configure(const AzTreeDev* d) {
-    const size_t sm = tree_smem(*d);
-    if (sm > 160 * 1024) return -1;
-    hipError_t e = hipFuncSetAttribute((const void*)az_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)az_begin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    return (int)e;
-}
-extern "C" void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode) {
-    hipLaunchKernelGGL(az_round_kernel, dim3(d->G), dim3(AZ_WAVE), tree_smem(*d), s, *d, phase_mask, mode);
+extern "C" int az_tree_configure(const AzTreeDev*) { return 0; }
+extern "C" void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode, int g0, int count) {
+    hipLaunchKernelGGL(az_round_kernel, dim3(count), dim3(AZ_WAVE), tree_smem(*d), s, *d, phase_mask, mode, g0);
 }
 extern "C" void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget) {
     hipLaunchKernelGGL(az_begin_kernel, dim3(d->G), dim3(AZ_WAVE), tree_smem(*d), s, *d, budget);

@@ -185,7 +185,7 @@ def main():
         A = N * N
         C = Cs[0]
         sims = sims_all                                    # counted on the device, one per backup
-        B = G * args.leaves                                # boards per evaluation launch
+        B = eng.selfplay_batch() * NC                      # boards per evaluation launch (x NC: divided again below)
         conv_flops = 2.0 * 9 * A * C * C * B               # one 3x3 conv over B boards, real cells only
         kernel = "az_conv3x3_kernel"
         if eng.tower_is_fused():                           # stem + all 2*num_res convs in one launch

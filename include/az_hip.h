@@ -171,6 +171,8 @@ int az_profile_enable(az_ctx*, int every);
 /* 1 when the tower runs as ONE launch per evaluation (az_tower_fused_kernel:
  * C <= 128 and (N+1)^2 <= 256), 0 when it runs one launch per convolution. */
 int az_tower_is_fused(const az_ctx*);
+/* Boards per evaluator launch during az_selfplay_run: G * leaves_per_round. */
+int az_selfplay_batch(const az_ctx*);
 int az_profile_read(az_ctx*, double* conv_avg_us, int64_t* conv_launches,
                     double* tree_avg_us, int64_t* tree_launches);
 
