@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--leaves", type=int, default=1,
                     help="descents per tree per round (1 = the reference at nthreads=1, bit-exact; >1 = its nthreads=L "
                          "in a fixed order, evaluation batch = games x leaves)")
+    ap.add_argument("--no-overlap-probe", action="store_true",
+                    help="skip the second, informational measurement with two contexts per GPU")
     ap.add_argument("--full-games", type=float, default=0.0,
                     help="after the timed region keep playing for this many seconds and report finished games/hour")
     args = ap.parse_args()
@@ -152,6 +154,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     prof = eng.profile_read()
+    fused, batch = eng.tower_is_fused(), eng.selfplay_batch()
     sts = [e.stats() for e in engs]
     st = {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
     sims_local = st["sims_backed_up"] - sims0              # simulations this rank backed up inside the timed region
@@ -181,14 +184,50 @@ def main():
                       "mean_game_length": (st2["moves"] - m0) / max(1, st2["games"] - g0),
                       "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"]}
 
+    overlap = None
+    if NC == 1 and not args.no_overlap_probe and G % 2 == 0 and args.full_games <= 0:
+        # Informational second measurement, never `value`: the same games as two contexts on two streams.
+        # A tree block fits on a CU beside a resident tower workgroup, so one context's tree round runs
+        # under the other's tower.  Launches of the two contexts overlap in time, which is why the
+        # headline and its roofline stay on the single-stream run above (clean per-launch durations).
+        for e in engs:
+            e.close()
+        engs = [capi.Engine(N, K, G // 2, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
+                            device=local_rank, game_slot_base=rank * G + i * (G // 2), precision=prec,
+                            leaves_per_round=args.leaves) for i in range(2)]
+        for e in engs:
+            if use_dist:
+                e.load_weights_dev(wt.data_ptr(), nw)
+            else:
+                e.load_weights(blob)
+            e.selfplay_begin(budget)
+        run(args.warmup)
+        barrier()
+        s0 = sum(e.stats()["sims_backed_up"] for e in engs)
+        t1 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        el2 = time.perf_counter() - t1
+        s1 = sum(e.stats()["sims_backed_up"] for e in engs) - s0
+        if use_dist:
+            t = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+            t = torch.tensor([s1], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            s1 = int(t.item())
+        overlap = {"contexts_per_gpu": 2, "value": s1 / el2, "unit": "sims/s", "ms_per_step": el2 / args.steps * 1e3,
+                   "note": "same games as two contexts on two streams (bench.py --contexts 2): tree rounds run under the "
+                           "other context's tower; informational, launches overlap so no per-launch roofline here"}
+
     if rank == 0:
         A = N * N
         C = Cs[0]
         sims = sims_all                                    # counted on the device, one per backup
-        B = eng.selfplay_batch() * NC                      # boards per evaluation launch (x NC: divided again below)
+        B = batch * NC                      # boards per evaluation launch (x NC: divided again below)
         conv_flops = 2.0 * 9 * A * C * C * B               # one 3x3 conv over B boards, real cells only
         kernel = "az_conv3x3_kernel"
-        if eng.tower_is_fused():                           # stem + all 2*num_res convs in one launch
+        if fused:                           # stem + all 2*num_res convs in one launch
             conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * B) / NC   # per launch of one context
             kernel = "az_tower_fused_kernel"
         conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
@@ -217,6 +256,7 @@ def main():
                          "tree_round_avg_us": prof["tree_avg_us"]},
         }
         line["full_games"] = games_info
+        line["two_context_overlap"] = overlap
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, N, K, budget, 16)
         print(json.dumps(line), flush=True)
