@@ -1,0 +1,111 @@
+"""Edge cases of the search / env entry points on the GPU, each against the oracle's
+restatement of the reference's behaviour (bit-exact) or against the reference's error rule."""
+import numpy as np
+import pytest
+
+import azo
+from alphazero_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(N, K, G, budget, **kw):
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=max(budget, 8), **kw)
+    noise = np.stack([azo.dirichlet(40 + g, N * N)[0] for g in range(G)])
+    eng.set_noise(noise)
+    eng.env_reset()
+    return eng, noise
+
+
+@pytest.mark.parametrize("budget", [-3, 0, 1, 2])
+def test_budget_below_one_still_runs_one_simulation(budget):
+    """mcts.hpp:161-174: the do/while body runs once even for iter_budget <= 0."""
+    N, K, G = 5, 4, 3
+    eng, noise = _fresh(N, K, G, budget)
+    out = eng.search(budget)
+    for g in range(G):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        ref = m.search([], budget, noise[g])
+        assert np.array_equal(out[g], ref)
+        assert eng.tree_canonical(g) == azo.canonical_tree(m.dump())
+        assert m.root_n() == 1 + max(budget, 1)
+
+
+def test_repeated_search_on_the_same_root_accumulates():
+    """generate.cpp:77,84: warm-up search and the move's search share the root (find() hit with
+    an identical history): visit counts add up."""
+    N, K, G, budget = 7, 5, 2, 60
+    eng, noise = _fresh(N, K, G, budget)
+    orc = [azo.MCTS(N, K, 3.0, 3.0, "hash") for _ in range(G)]
+    for rep in range(3):
+        out = eng.search(budget)
+        for g in range(G):
+            ref = orc[g].search([], budget, noise[g])
+            assert np.array_equal(out[g], ref)
+            assert orc[g].root_n() == 1 + (rep + 1) * budget
+            assert eng.tree_canonical(g) == azo.canonical_tree(orc[g].dump())
+
+
+def test_tree_clear_matches_oracle_clear():
+    """MCTS::clear (mcts.hpp:462-465) drops the tree: the next search starts from a fresh root
+    and draws fresh root noise."""
+    N, K, G, budget = 5, 4, 2, 40
+    eng, noise = _fresh(N, K, G, budget)
+    first = eng.search(budget)
+    eng.tree_clear()
+    again = eng.search(budget)
+    assert np.array_equal(first, again)
+    for g in range(G):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        m.search([], budget, noise[g])
+        m.clear()
+        assert np.array_equal(again[g], m.search([], budget, noise[g]))
+
+
+def test_search_on_a_finished_game_returns_zeros_and_leaves_others_alone():
+    N, K, G, budget = 3, 3, 2, 30
+    eng, noise = _fresh(N, K, G, budget)
+    # game 0: player 0 wins on the top row; game 1: two moves only
+    eng.env_load([[0, 3, 1, 4, 2], [4, 0]])
+    out = eng.search(budget)
+    assert not out[0].any()
+    m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+    assert np.array_equal(out[1], m.search([4, 0], budget, noise[1]))
+    with pytest.raises(ValueError):
+        azo.MCTS(N, K, 3.0, 3.0, "hash").search([0, 3, 1, 4, 2], budget, noise[0])   # the oracle refuses it too
+
+
+def test_env_load_rejects_illegal_histories():
+    N, K, G = 3, 3, 1
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=8)
+    with pytest.raises(capi.AzError, match="illegal move"):
+        eng.env_load([[4, 4]])                          # occupied cell
+    with pytest.raises(capi.AzError, match="illegal move"):
+        eng.env_load([[9]])                             # off the board
+    with pytest.raises(capi.AzError, match="after the game ended"):
+        eng.env_load([[0, 3, 1, 4, 2, 5]])              # move after a win
+
+
+def test_arena_overflow_is_reported_not_silently_truncated():
+    N, K, G = 7, 5, 2
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=64, node_cap=16)
+    eng.env_reset()
+    with pytest.raises(capi.AzError, match="arena full"):
+        eng.search(64)
+    with pytest.raises(capi.AzError, match="exceeds az_config.max_budget"):
+        capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=8).search(4000)
+
+
+def test_search_is_deterministic_across_contexts_and_slots():
+    """Same position, same noise: every slot of every context returns the same bits."""
+    N, K, G, budget = 9, 5, 4, 120
+    noise = np.tile(azo.dirichlet(5, N * N)[0], (G, 1))
+    outs = []
+    for _ in range(2):
+        eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget)
+        eng.set_noise(noise)
+        eng.env_load([[40, 41]] * G)
+        outs.append(eng.search(budget))
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+    assert all(np.array_equal(outs[0][0], outs[0][g]) for g in range(G))
