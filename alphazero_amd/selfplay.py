@@ -63,24 +63,43 @@ def gather_rows(cells, to_move, policy, reward, dst=0, device="cpu"):
     return None
 
 
-def run_selfplay(N, K, games_per_gpu, budget, Cs, blob_on_rank0, rounds, local_rank=0, seed=0, sink=None):
+def run_selfplay(N, K, games_per_gpu, budget, Cs, blob_on_rank0, rounds, local_rank=0, seed=0, sink=None, contexts=2):
     """Rank-sharded device self-play.  blob_on_rank0: weights on rank 0 (None
     elsewhere).  sink(cells, to_move, policy, reward) is called on rank 0 with
-    the gathered rows.  Needs an MI355X per rank."""
+    the gathered rows.  Needs an MI355X per rank.
+
+    A rank's games run as `contexts` engine contexts on their own HIP streams: a tree
+    block fits on a CU beside a resident tower workgroup, so one context's tree round
+    executes under the other's tower kernel."""
     from . import capi
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, _ = shard_slots(rank, world, games_per_gpu)
-    eng = capi.Engine(N, K, games_per_gpu, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=seed,
-                      device=local_rank, game_slot_base=lo)
-    wt = broadcast_weights(blob_on_rank0, eng.weights_size(), 0, torch.device("cuda", local_rank))
+    if contexts < 1 or games_per_gpu < 2 * contexts:
+        contexts = 1
+    sizes = [games_per_gpu // contexts + (1 if i < games_per_gpu % contexts else 0) for i in range(contexts)]
+    engs, first = [], lo
+    for n in sizes:
+        engs.append(capi.Engine(N, K, n, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=seed,
+                                device=local_rank, game_slot_base=first))
+        first += n
+    wt = broadcast_weights(blob_on_rank0, engs[0].weights_size(), 0, torch.device("cuda", local_rank))
     torch.cuda.synchronize()
-    eng.load_weights_dev(wt.data_ptr(), wt.numel())
-    eng.selfplay_begin(budget)
-    eng.selfplay_run(rounds)
-    rows = eng.replay_drain()
+    for e in engs:
+        e.load_weights_dev(wt.data_ptr(), wt.numel())
+        e.selfplay_begin(budget)
+    done = 0
+    while done < rounds:                                   # slices keep every stream fed
+        k = min(16, rounds - done)
+        for e in engs:
+            e.selfplay_run(k)
+        done += k
+    parts = [e.replay_drain() for e in engs]
+    rows = tuple(np.concatenate([p[i] for p in parts], 0) for i in range(4))
     got = gather_rows(*rows, dst=0, device=torch.device("cuda", local_rank))
     if got is not None and sink is not None:
         sink(*got)
-    st = eng.stats()
-    eng.close()
+    sts = [e.stats() for e in engs]
+    st = {k: (max if k in ("max_nodes", "max_edges", "rounds") else sum)(x[k] for x in sts) for k in sts[0]}
+    for e in engs:
+        e.close()
     return st

@@ -16,3 +16,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+# torch first: a process must hold ONE HIP runtime, and torch brings its own copy; libazhip.so
+# (loaded later through ctypes) then binds to the runtime that is already resident
+try:
+    import torch  # noqa: F401,E402
+except Exception:  # noqa: BLE001
+    pass

@@ -1,7 +1,10 @@
 """BASELINE.json's full-size configurations on the GPU, checked through
 size-independent properties plus bit-exact spot checks against the oracle."""
+import os
+
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libazhip: one HIP runtime per process, torch's)
 
 import azo
 from alphazero_amd import capi, synth
@@ -116,3 +119,39 @@ def test_selfplay_rows_are_consistent_full_size():
     first = (cells.sum(1) == 0)
     assert first.any()
     assert np.allclose(s[first], 2 * budget / (2 * budget + 1.0), atol=2e-5)
+
+
+def test_run_selfplay_driver_two_contexts_single_rank():
+    """alphazero_amd.selfplay.run_selfplay (the per-rank driver of the multi-GPU path) on one
+    rank over RCCL: two engine contexts on two streams, rows gathered to the sink, slot ranges
+    of the contexts disjoint, every row a valid (position, policy, reward) triple."""
+    import torch
+    import torch.distributed as dist
+    from alphazero_amd import selfplay, synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, K, G, budget = 7, 5, 24, 24
+        A = N * N
+        Cs = synth.NETCONFIG2
+        blob = synth.make_blob(N, 3, Cs, 3)
+        got = {}
+
+        def sink(cells, tm, pol, rew):
+            got.update(cells=cells, tm=tm, pol=pol, rew=rew)
+        st = selfplay.run_selfplay(N, K, G, budget, Cs, blob, rounds=budget * (A + 3), sink=sink, contexts=2)
+        assert st["games"] >= G and st["error_games"] == 0 and st["replay_dropped"] == 0
+        assert len(got["tm"]) > 0
+        sums = got["pol"].sum(1)
+        assert ((sums > 0.9) & (sums <= 1.0 + 1e-6)).all()
+        assert set(np.unique(got["rew"])) <= {-1.0, 0.0, 1.0}
+        assert (got["rew"][:, 0] == -got["rew"][:, 1]).all()
+        stones = (got["cells"] != 0).sum(1)
+        assert ((stones % 2) == got["tm"]).all()               # player 0 moves on even stone counts
+        assert (got["pol"][got["cells"] != 0] == 0).all()      # no visits on occupied cells
+    finally:
+        if own:
+            dist.destroy_process_group()
