@@ -174,7 +174,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     d.ring_cap = std::max(4 * G * A / 2, 4096);
     DA(ring_cells, (size_t)d.ring_cap * A); DA(ring_tomove, d.ring_cap);
     DA(ring_policy, (size_t)d.ring_cap * A); DA(ring_reward, 2 * (size_t)d.ring_cap);
-    DA(counters, 16);
+    DA(counters, 16); DA(g_evals, G); DA(g_hw_nodes, G); DA(g_hw_edges, G);
 #undef DA
     HIPCHK(hipMemset(d.root_hist_len, 0xFF, sizeof(int) * G));      // -1: no tree
     {   // uniform noise default so an unset buffer is still a distribution
@@ -522,6 +522,17 @@ extern "C" int az_set_noise(az_ctx* c, const float* noise) {
 extern "C" int az_tree_clear(az_ctx* c) {
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
+    {   // keep the arena high-water marks of the trees that are about to be dropped
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<int> nn(G), ne(G), hn(G), he(G);
+        HIPCHK(hipMemcpy(nn.data(), c->d.n_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ne.data(), c->d.n_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hn.data(), c->d.g_hw_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(he.data(), c->d.g_hw_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; ++g) { hn[g] = std::max(hn[g], nn[g]); he[g] = std::max(he[g], ne[g]); }
+        HIPCHK(hipMemcpy(c->d.g_hw_nodes, hn.data(), sizeof(int) * G, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d.g_hw_edges, he.data(), sizeof(int) * G, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemsetAsync(c->d.root_hist_len, 0xFF, sizeof(int) * G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.n_nodes, 0, sizeof(int) * G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.n_edges, 0, sizeof(int) * G, c->stream));
@@ -683,6 +694,9 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     c->d.budget = budget > 1 ? budget : 1;
     c->mode = AZ_MODE_SELFPLAY;
     HIPCHK(hipMemsetAsync(c->d.counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d.g_evals, 0, sizeof(unsigned long long) * c->cfg.G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.g_hw_nodes, 0, sizeof(int) * c->cfg.G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.g_hw_edges, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.err, 0, sizeof(int) * c->cfg.G, c->stream));
     az_launch_selfplay_begin(c->stream, &c->d);
     // issue the first evaluation so that every later round is evaluate -> tree
@@ -734,16 +748,32 @@ extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_m
 extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const int G = c->cfg.G;
     unsigned long long k[16];
     HIPCHK(hipMemcpy(k, c->d.counters, sizeof k, hipMemcpyDeviceToHost));
-    std::vector<int> err(c->cfg.G);
-    HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * c->cfg.G, hipMemcpyDeviceToHost));
+    std::vector<int> err(G), st(G), sd(G), nn(G), ne(G), hn(G), he(G);
+    std::vector<unsigned long long> ev(G);
+    HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st.data(), c->d.status, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sd.data(), c->d.sims_done, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nn.data(), c->d.n_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ne.data(), c->d.n_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hn.data(), c->d.g_hw_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(he.data(), c->d.g_hw_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ev.data(), c->d.g_evals, sizeof(unsigned long long) * G, hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
-    s->sims = (int64_t)k[0]; s->evals = (int64_t)k[1]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
+    s->sims = (int64_t)k[0]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
     s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
-    s->max_nodes = (int32_t)k[6]; s->max_edges = (int32_t)k[7]; s->sims_backed_up = (int64_t)k[8];
     s->rounds = c->rounds;
-    for (int e : err) s->error_games += e != 0;
+    // simulations backed up = those of completed searches + the progress of searches in flight
+    s->sims_backed_up = (int64_t)k[0];
+    for (int g = 0; g < G; ++g) {
+        s->evals += (int64_t)ev[g];
+        if (st[g] == AZ_ST_RUN) s->sims_backed_up += sd[g];
+        s->max_nodes = std::max(s->max_nodes, std::max(hn[g], nn[g]));
+        s->max_edges = std::max(s->max_edges, std::max(he[g], ne[g]));
+        s->error_games += err[g] != 0;
+    }
     return AZ_OK;
 }
 

@@ -86,9 +86,12 @@ struct AzTreeDev {
     uint8_t*  ring_tomove;      // [ring_cap]
     float*    ring_policy;      // [ring_cap][A]
     float*    ring_reward;      // [ring_cap][2]
-    // counters: [0] sims [1] evals [2] moves [3] games [4] ring rows [5] dropped
-    // [6] max nodes [7] max edges [8] simulations backed up (counted one by one)
+    // counters touched at most once per move: [0] sims of completed searches [2] moves [3] games
+    // [4] ring rows [5] dropped.  Everything counted per round lives per game (no hot shared word):
     unsigned long long* counters;
+    unsigned long long* g_evals;        // [G] boards submitted to the evaluator
+    int*      g_hw_nodes;       // [G] arena high-water marks, noted when a tree shrinks
+    int*      g_hw_edges;       // [G]
 };
 
 __host__ __device__ inline unsigned long long az_splitmix64(unsigned long long z) {

@@ -15,6 +15,16 @@
 #include "az_dev.h"
 
 #define AZ_WAVE 64
+// Optional phase timing (build with -DAZ_TREE_TIMING): block 7 stamps the 100 MHz clock.
+#ifdef AZ_TREE_TIMING
+__device__ unsigned long long az_tree_ts[16];
+#define TTS(slot_) do { if (blockIdx.x == 7 && threadIdx.x == 0) az_tree_ts[slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int az_tree_timing_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(az_tree_ts), sizeof(unsigned long long) * 16);
+}
+#else
+#define TTS(slot_) do {} while (0)
+#endif
 #define AZ_CELLS_MAX 512
 // LDS of a tree block: board bytes, then per-descent undo records (old n, old v, action): 6.5 KB,
 // small enough to sit on a CU beside a resident tower workgroup
@@ -105,6 +115,12 @@ __device__ void az_device_noise(const AzTreeDev& d, int g, int count) {
     __syncthreads();
 }
 
+// high-water marks of the arena, recorded whenever a tree is about to shrink
+__device__ __forceinline__ void az_note_high_water(const AzTreeDev& d, int g) {
+    d.g_hw_nodes[g] = max(d.g_hw_nodes[g], d.n_nodes[g]);
+    d.g_hw_edges[g] = max(d.g_hw_edges[g], d.n_edges[g]);
+}
+
 // ------------------------------------------------------------ re-root (find)
 // Copies the subtree under `target` into the other arena in BFS order so the
 // new root is node 0 (the reference just drops the shared_ptr to the old
@@ -154,6 +170,7 @@ __device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n) {
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        az_note_high_water(d, g);
         d.arena[g] = ar ^ 1;
         d.n_nodes[g] = new_count;
         d.n_edges[g] = new_edges;
@@ -166,7 +183,7 @@ __device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n) {
 }
 
 __device__ void az_drop_tree(const AzTreeDev& d, int g) {
-    if (threadIdx.x == 0) { d.root_hist_len[g] = -1; d.n_nodes[g] = 0; d.n_edges[g] = 0; d.root_n[g] = 0; }
+    if (threadIdx.x == 0) { az_note_high_water(d, g); d.root_hist_len[g] = -1; d.n_nodes[g] = 0; d.n_edges[g] = 0; d.root_n[g] = 0; }
     __syncthreads();
 }
 
@@ -227,6 +244,7 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     const int* path = d.path + (size_t)slot * d.path_cap;
     const int rt = uni(d.to_move[g]);
     const int hl = uni(d.hist_len[g]);
+    TTS(8);
 
     if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
         // the leaf position = root position + the moves along the path (one lane per ply:
@@ -269,14 +287,13 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
             d.n_nodes[g] = nn + 1;
             d.n_edges[g] = ne0 + base;
             if (!is_root) E[path[plen - 1]].child = nn;                 // leaf->add (mcts.hpp:316)
-            atomicMax(&d.counters[6], (unsigned long long)(nn + 1));
-            atomicMax(&d.counters[7], (unsigned long long)(ne0 + base));
         }
         __syncthreads();
         // restore the root position in LDS
         for (int t = threadIdx.x; t < plen; t += AZ_WAVE) s_cells[s_act[t]] = 0;
         __syncthreads();
     }
+    TTS(9);
     if (pend == AZ_PEND_ROOT) {                                         // mcts.hpp:412-413
         if (threadIdx.x == 0) {
             d.root_n[g] = 1;
@@ -297,7 +314,6 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         if (threadIdx.x == 0) {
             d.root_n[g] = d.root_n[g] + 1;
             d.sims_done[g] = d.sims_done[g] + 1;
-            atomicAdd(&d.counters[8], 1ull);
         }
     }
     if (threadIdx.x == 0) d.pending[slot] = AZ_PEND_NONE;
@@ -317,7 +333,7 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     const int hl = uni(d.hist_len[g]);
     if (uni(d.root_hist_len[g]) < 0) {                                  // fresh root: evaluate the root board
         az_write_planes(d, slot, s_cells, rt);
-        if (threadIdx.x == 0) { d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; atomicAdd(&d.counters[1], 1ull); }
+        if (threadIdx.x == 0) { d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; d.g_evals[g] = d.g_evals[g] + 1ull; }
         return 1;
     }
     int* s_old_n = s_old;
@@ -417,7 +433,7 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         d.pending[slot] = pend;
         d.path_len[slot] = depth;
         if (pend == AZ_PEND_TERMINAL) { d.pend_result[2 * slot] = t0; d.pend_result[2 * slot + 1] = t1; }
-        else atomicAdd(&d.counters[1], 1ull);
+        else d.g_evals[g] = d.g_evals[g] + 1ull;                        // per game: no hot shared counter in the round
     }
     __syncthreads();
     for (int t = threadIdx.x; t < depth; t += AZ_WAVE) s_cells[s_act[t]] = 0;
@@ -573,16 +589,21 @@ az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
     uint8_t* s_cells = smem;
     int* s_old = (int*)(smem + AZ_CELLS_MAX);
     const int g = g0 + blockIdx.x;                                      // a launch covers games [g0, g0 + gridDim.x)
+    TTS(0);
     if (uni(d.status[g]) != AZ_ST_RUN) return;
+    TTS(1);
     for (int c = threadIdx.x; c < d.A; c += AZ_WAVE) s_cells[c] = d.cells[(size_t)g * d.A + c];
     __syncthreads();
+    TTS(2);
     if (phase_mask & 1)
         for (int k = 0; k < d.L; ++k) {
             az_apply(d, g, k, s_cells, s_old + 2 * AZ_CELLS_MAX);
             if (uni(d.status[g]) != AZ_ST_RUN) return;
         }
+    TTS(3);
     if (!(phase_mask & 2)) return;
     if (uni(d.pending[g * d.L]) != AZ_PEND_NONE) return;                // select already issued
+    TTS(4);
     if (uni(d.sims_done[g]) >= uni(d.sims_target[g])) {
         if (threadIdx.x == 0) atomicAdd(&d.counters[0], (unsigned long long)d.sims_done[g]);
         if (mode == AZ_MODE_SELFPLAY && uni(d.move_idx[g]) < 0) {
@@ -602,8 +623,10 @@ az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
     }
     // up to L descents, never more than the simulations still owed (mcts.hpp:161-174)
     const int owed = uni(d.sims_target[g]) - uni(d.sims_done[g]);
+    TTS(5);
     for (int k = 0; k < d.L && k < owed; ++k)
         if (az_select(d, g, k, s_cells, s_old)) break;
+    TTS(6);
 }
 
 // search_probs entry: root reuse decision (mcts.hpp:121) for every game.
