@@ -159,7 +159,6 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     DA(game_over, G); DA(final_reward, 2 * (size_t)G);
     DA(arena, G);
     for (int a = 0; a < 2; ++a) {
-        AZCHK(dalloc(c, &d.nodes[a], (size_t)G * d.node_cap, false));
         AZCHK(dalloc(c, &d.edges[a], (size_t)G * d.edge_cap, false));
         AZCHK(dalloc(c, &d.eact[a], (size_t)G * d.edge_cap, false));
     }
@@ -672,16 +671,29 @@ extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int
     *n_nodes = nn; *n_edges = ne;
     if (node_cap == 0 && edge_cap == 0) return AZ_OK;
     if (node_cap < nn || edge_cap < ne) return fail(AZ_E_ARG, "dump buffers too small (%d nodes, %d edges)", nn, ne);
-    std::vector<int2> nd(nn);
     std::vector<AzEdge> ed(ne);
     std::vector<uint16_t> ea(ne);
-    HIPCHK(hipMemcpy(nd.data(), c->d.nodes[ar] + (size_t)game * c->d.node_cap, sizeof(int2) * nn, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ed.data(), c->d.edges[ar] + (size_t)game * c->d.edge_cap, sizeof(AzEdge) * ne, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ea.data(), c->d.eact[ar] + (size_t)game * c->d.edge_cap, 2 * (size_t)ne, hipMemcpyDeviceToHost));
-    for (int i = 0; i < nn; ++i) { node_first[i] = nd[i].x; node_count[i] = nd[i].y; }
     for (int i = 0; i < ne; ++i) {
         edge_p[i] = ed[i].p; edge_n[i] = ed[i].n; edge_v[i] = ed[i].v; edge_child[i] = ed[i].child; edge_action[i] = ea[i];
     }
+    // On the device a node IS its block of child edges (an edge links to the first edge of its child's
+    // block; an expanded node l plies below the root has A - root_history - l children).  The dump
+    // numbers the blocks in BFS order from the root (node 0) and rewrites the links to those numbers.
+    int count = 0;
+    if (nn > 0) { node_first[0] = 0; node_count[0] = c->A - rhl; count = 1; }
+    for (int i = 0; i < count; ++i) {
+        const int fe = node_first[i], k = node_count[i];
+        if (fe < 0 || fe + k > ne) return fail(AZ_E_STATE, "game %d: arena links are corrupt", game);
+        for (int e = fe; e < fe + k; ++e)
+            if (ed[e].child >= 0) {
+                if (count >= nn) return fail(AZ_E_STATE, "game %d: more linked blocks than expanded nodes", game);
+                node_first[count] = ed[e].child; node_count[count] = k - 1;
+                edge_child[e] = count++;
+            }
+    }
+    if (count != nn) return fail(AZ_E_STATE, "game %d: %d linked blocks but %d expanded nodes", game, count, nn);
     return AZ_OK;
 }
 

@@ -5,7 +5,10 @@
 
 // One child stub = one reference Node before add() (node.hpp:21-22,63-67):
 // prior p, visits n, total value v; q is v/n (recomputed, identical bits).
-// child: >=0 id of the expanded node, -1 stub, -2/-3/-4 terminal leaf whose
+// child: >=0 the expanded child node = index of the first edge of ITS block of child edges
+// (a node is nothing but that block: one edge per empty cell of its position, so an expanded
+// node l plies below the root owns A - root_history - l consecutive edges and the root's block
+// starts at edge 0), -1 stub, -2/-3/-4 terminal leaf whose
 // stored reward is {+1,-1} / {-1,+1} / {0,0} (Node::terminal_add, node.hpp:36-42),
 // -5 stub whose evaluation was issued in the current round (the reference holds
 // the node's lock over that span, mcts.hpp:224-231).
@@ -44,10 +47,9 @@ struct AzTreeDev {
 
     // tree arenas (ping-pong for re-root compaction)
     int*      arena;            // [G] 0/1
-    int2*     nodes[2];         // [G][node_cap] {first_edge, num_edges}
     AzEdge*   edges[2];         // [G][edge_cap]
     uint16_t* eact[2];          // [G][edge_cap] action (cell index) of each edge
-    int*      n_nodes;          // [G]
+    int*      n_nodes;          // [G] expanded nodes (= edge blocks) in the arena
     int*      n_edges;          // [G]
     int*      root_n;           // [G]
     int*      root_hist_len;    // [G] -1 = no tree

@@ -26,9 +26,10 @@ extern "C" int az_tree_timing_read(unsigned long long* out) {
 #define TTS(slot_) do {} while (0)
 #endif
 #define AZ_CELLS_MAX 512
-// LDS of a tree block: board bytes, then per-descent undo records (old n, old v, action): 6.5 KB,
+// LDS of a tree block: board bytes, then per-descent records (old n, old v, action, edge): 7.5 KB,
 // small enough to sit on a CU beside a resident tower workgroup
-#define AZ_SMEM_FIXED (AZ_CELLS_MAX + 3 * AZ_CELLS_MAX * 4)
+#define AZ_PATH_MAX 448          // plies of one descent: A + 1 <= 442
+#define AZ_SMEM_FIXED (AZ_CELLS_MAX + 4 * AZ_PATH_MAX * 4)
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
@@ -122,34 +123,36 @@ __device__ __forceinline__ void az_note_high_water(const AzTreeDev& d, int g) {
 }
 
 // ------------------------------------------------------------ re-root (find)
-// Copies the subtree under `target` into the other arena in BFS order so the
-// new root is node 0 (the reference just drops the shared_ptr to the old
-// root, mcts.hpp:417-420).  Returns false if the arena bookkeeping is corrupt.
-__device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n) {
+// Copies the subtree whose root block starts at edge `target_fe` into the other arena in
+// BFS order, so that the new root's block starts at edge 0 (the reference just drops the
+// shared_ptr to the old root, mcts.hpp:417-420).  A node is its block of child edges; an
+// expanded node at BFS level l below the new root has A - hist_len - l of them (one per
+// empty cell), so block sizes need no storage and a child's place in the new arena is
+// known the moment it is queued.
+__device__ void az_reroot(const AzTreeDev& d, int g, int target_fe, int target_n) {
     const int ar = uni(d.arena[g]);
     const AzEdge* E0 = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* A0 = d.eact[ar] + (size_t)g * d.edge_cap;
-    const int2* N0 = d.nodes[ar] + (size_t)g * d.node_cap;
     AzEdge* E1 = d.edges[ar ^ 1] + (size_t)g * d.edge_cap;
     uint16_t* A1 = d.eact[ar ^ 1] + (size_t)g * d.edge_cap;
-    int2* N1 = d.nodes[ar ^ 1] + (size_t)g * d.node_cap;
-    // BFS queue of old node ids in HBM (the block's LDS stays small enough to share a CU
+    // BFS queue of old block starts in HBM (the block's LDS stays small enough to share a CU
     // with a resident tower workgroup); the wave reads it 64 entries at a time
     int* queue = d.queue + (size_t)g * d.node_cap;
-    if (threadIdx.x == 0) queue[0] = target;
+    const int ne_root = d.A - uni(d.hist_len[g]);
+    if (threadIdx.x == 0) queue[0] = target_fe;
     __syncthreads();
     int new_count = 1, new_edges = 0;
+    int level = 0, level_end = 1, alloc = ne_root;                      // alloc: first free edge of the new arena
     int win_base = 0, win_end = 0, win_val = 0;                         // queue[win_base + lane] for entries < win_end
     for (int i = 0; i < new_count; ++i) {
+        if (i == level_end) { ++level; level_end = new_count; }
         if (i >= win_end) {
             win_base = i;
             win_end = min(i + AZ_WAVE, new_count);
             win_val = win_base + (int)threadIdx.x < win_end ? queue[win_base + threadIdx.x] : 0;
         }
-        const int old = __shfl(win_val, i - win_base, AZ_WAVE);
-        const int2 nd = N0[old];
-        const int fe = uni(nd.x), ne = uni(nd.y);
-        if (threadIdx.x == 0) N1[i] = make_int2(new_edges, ne);
+        const int fe = __shfl(win_val, i - win_base, AZ_WAVE);
+        const int ne = ne_root - level, ne_child = ne - 1;
         for (int c = 0; c < ne; c += AZ_WAVE) {
             const int k = c + threadIdx.x;
             const bool valid = k < ne;
@@ -159,12 +162,13 @@ __device__ void az_reroot(const AzTreeDev& d, int g, int target, int target_n) {
             const bool has = valid && e.child >= 0;
             const unsigned long long m = __ballot(has);
             if (has) {
-                const int idx = new_count + __popcll(m & lanemask_lt());
-                queue[idx] = e.child;
-                e.child = idx;
+                const int rank = __popcll(m & lanemask_lt());
+                queue[new_count + rank] = e.child;
+                e.child = alloc + rank * ne_child;
             }
             if (valid) { E1[new_edges + k] = e; A1[new_edges + k] = act; }
             new_count += __popcll(m);
+            alloc += __popcll(m) * ne_child;
         }
         new_edges += ne;
         __syncthreads();
@@ -204,12 +208,10 @@ __device__ int az_make_root(const AzTreeDev& d, int g) {
     const int ar = uni(d.arena[g]);
     const AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
-    const int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
-    int node = 0, tn = 0;
+    int fe = 0, tn = 0;                                                // the root's block starts at edge 0
     for (int t = rhl; t < hl; ++t) {                                   // node.hpp:93-100
         const int action = H[t];
-        const int2 nd = ND[node];
-        const int fe = uni(nd.x), ne = uni(nd.y);
+        const int ne = d.A - t;                                        // one child per empty cell after t plies
         int found = -1;
         for (int k = threadIdx.x; k < ne; k += AZ_WAVE)
             if (EA[fe + k] == action) found = k;
@@ -221,10 +223,10 @@ __device__ int az_make_root(const AzTreeDev& d, int g) {
         // a never-visited stub has no state: searching from it is undefined in
         // the reference; a terminal child cannot be current while !game_over
         if (child < 0) { az_drop_tree(d, g); return 1; }
-        node = child;
+        fe = child;
         tn = uni(e.n);
     }
-    az_reroot(d, g, node, tn);
+    az_reroot(d, g, fe, tn);
     return 1;
 }
 
@@ -239,7 +241,6 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     const int ar = uni(d.arena[g]);
     AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
-    int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
     const int plen = uni(d.path_len[slot]);
     const int* path = d.path + (size_t)slot * d.path_cap;
     const int rt = uni(d.to_move[g]);
@@ -283,10 +284,9 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
             base += __popcll(m);
         }
         if (threadIdx.x == 0) {
-            ND[nn] = make_int2(ne0, base);
             d.n_nodes[g] = nn + 1;
             d.n_edges[g] = ne0 + base;
-            if (!is_root) E[path[plen - 1]].child = nn;                 // leaf->add (mcts.hpp:316)
+            if (!is_root) E[path[plen - 1]].child = ne0;                // leaf->add (mcts.hpp:316): link = its block's first edge
         }
         __syncthreads();
         // restore the root position in LDS
@@ -336,22 +336,24 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         if (threadIdx.x == 0) { d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; d.g_evals[g] = d.g_evals[g] + 1ull; }
         return 1;
     }
+    // per-ply records of this descent, all in LDS: while descending the wave issues loads only;
+    // the virtual-loss updates and the path go to HBM in one parallel batch at the end
     int* s_old_n = s_old;
-    float* s_old_v = (float*)(s_old + AZ_CELLS_MAX);
-    int* s_act = s_old + 2 * AZ_CELLS_MAX;
+    float* s_old_v = (float*)(s_old + AZ_PATH_MAX);
+    int* s_act = s_old + 2 * AZ_PATH_MAX;
+    int* s_path = s_old + 3 * AZ_PATH_MAX;
     const int ar = uni(d.arena[g]);
     AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
-    const int2* ND = d.nodes[ar] + (size_t)g * d.node_cap;
     int* path = d.path + (size_t)slot * d.path_cap;
     const float vl = d.vl;
     const float cpf = (float)d.c_puct_i;
 
-    int node = 0, par_n = uni(d.root_n[g]), player = rt, depth = 0, pend = AZ_PEND_NONE;
+    // a node is its block of child edges: the root's starts at edge 0, a child's at edge.child; an
+    // expanded node has one child per empty cell, so the block size needs no load either
+    int fe = 0, ne = A - hl, par_n = uni(d.root_n[g]), player = rt, depth = 0, pend = AZ_PEND_NONE;
     float t0 = 0.f, t1 = 0.f;
-    for (;;) {
-        const int2 nd = ND[node];
-        const int fe = uni(nd.x), ne = uni(nd.y);
+    for (;; --ne) {
         const double s = sqrt((double)(par_n - 1));                     // node.hpp:54 sqrt(int) -> double
         float best_val = -100.f;                                        // mcts.hpp:355
         int best_k = -1;
@@ -385,27 +387,31 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         e.p = __shfl(be.p, owner, AZ_WAVE); e.n = __shfl(be.n, owner, AZ_WAVE);
         e.v = __shfl(be.v, owner, AZ_WAVE); e.child = __shfl(be.child, owner, AZ_WAVE);
         const int action = __shfl(bact, owner, AZ_WAVE);
-        if (threadIdx.x == 0) { s_old_n[depth] = e.n; s_old_v[depth] = e.v; s_act[depth] = action; }
-        e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227
-        e.v = e.v - vl;
         if (threadIdx.x == 0) {
-            E[ei].n = e.n; E[ei].v = e.v;
-            path[depth] = ei;
+            s_old_n[depth] = e.n; s_old_v[depth] = e.v; s_act[depth] = action; s_path[depth] = ei;
             s_cells[action] = (uint8_t)(player + 1);
         }
-        __syncthreads();
+        e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227 (stored below)
+        e.v = e.v - vl;
+        // the block is ONE wave: its LDS traffic is in order, no barrier needed to go one level deeper
+        __builtin_amdgcn_wave_barrier();
         const int mover = player;
         player ^= 1;
         depth++;
         const int child = uni(e.child);
-        if (child >= 0) { node = child; par_n = uni(e.n); continue; }
-        if (child == AZ_CHILD_WAITING) {                                // undo: n, v and the board
-            for (int t = threadIdx.x; t < depth; t += AZ_WAVE) {
-                E[path[t]].n = s_old_n[t]; E[path[t]].v = s_old_v[t];
-                s_cells[s_act[t]] = 0;
-            }
+        if (child >= 0) { fe = child; par_n = uni(e.n); continue; }
+        __syncthreads();
+        if (child == AZ_CHILD_WAITING) {                                // nothing was stored yet: only the board to undo
+            for (int t = threadIdx.x; t < depth; t += AZ_WAVE) s_cells[s_act[t]] = 0;
             __syncthreads();
             return 1;
+        }
+        // the descent stands: virtual loss n += vl (int += float), v -= vl on every edge of the path
+        for (int t = threadIdx.x; t < depth; t += AZ_WAVE) {
+            const int pe = s_path[t];
+            E[pe].n = (int)((float)s_old_n[t] + vl);
+            E[pe].v = s_old_v[t] - vl;
+            path[t] = pe;
         }
         if (child <= -2) {                                              // stored terminal reward, mcts.hpp:232-233
             pend = AZ_PEND_TERMINAL;
@@ -451,10 +457,10 @@ __device__ void az_emit_policy(const AzTreeDev& d, int g) {
     const int ar = uni(d.arena[g]);
     const AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
-    const int2 nd = (d.nodes[ar] + (size_t)g * d.node_cap)[0];
+    const int ne = A - uni(d.hist_len[g]);                              // the root's block: edges [0, ne)
     const float rn = (float)uni(d.root_n[g]);
-    for (int k = threadIdx.x; k < nd.y; k += AZ_WAVE)
-        out[EA[nd.x + k]] = __fdiv_rn((float)E[nd.x + k].n, rn);
+    for (int k = threadIdx.x; k < ne; k += AZ_WAVE)
+        out[EA[k]] = __fdiv_rn((float)E[k].n, rn);
     __syncthreads();
 }
 
@@ -474,8 +480,7 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells) {
     const int ar = uni(d.arena[g]);
     const AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
-    const int2 nd = (d.nodes[ar] + (size_t)g * d.node_cap)[0];
-    const int fe = uni(nd.x), ne = uni(nd.y);
+    const int fe = 0, ne = A - uni(d.hist_len[g]);                      // the root's block
     int chosen = -1;
     if ((double)i < (double)d.avg_len[g] * 0.2) {                      // generate.cpp:88: sample ~ visits
         unsigned part = 0;
@@ -597,7 +602,7 @@ az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
     TTS(2);
     if (phase_mask & 1)
         for (int k = 0; k < d.L; ++k) {
-            az_apply(d, g, k, s_cells, s_old + 2 * AZ_CELLS_MAX);
+            az_apply(d, g, k, s_cells, s_old + 2 * AZ_PATH_MAX);
             if (uni(d.status[g]) != AZ_ST_RUN) return;
         }
     TTS(3);

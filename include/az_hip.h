@@ -141,9 +141,10 @@ int az_search_apply(az_ctx*, const float* policy, const float* value);
 int az_search_result(az_ctx*, float* out_policy, int32_t* root_n /* [G] or NULL */);
 int az_tree_clear(az_ctx*);                        /* MCTS::clear (mcts.hpp:462-465) */
 
-/* Parity introspection: raw arena of game g.  edges are {p,n,v,child}; child
- * >= 0 expanded node id, -1 stub, -2/-3/-4 terminal (p0 wins / p1 wins / draw).
- * Call with cap 0 to size.  Node 0 is the root. */
+/* Parity introspection: the arena of game g.  edges are {p,n,v,child}; child
+ * >= 0 expanded node id (nodes numbered in BFS order, node 0 is the root; node i owns edges
+ * [node_first[i], node_first[i] + node_count[i])), -1 stub, -2/-3/-4 terminal (p0 wins /
+ * p1 wins / draw).  Call with cap 0 to size. */
 int az_tree_dump(az_ctx*, int game, int node_cap, int edge_cap, int32_t* n_nodes, int32_t* n_edges,
                  int32_t* node_first, int32_t* node_count,
                  float* edge_p, int32_t* edge_n, float* edge_v, int32_t* edge_child, int32_t* edge_action);
