@@ -468,7 +468,7 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
 
 // Register budget: 400 of the SIMD's 512 per lane (amdgpu_num_vgpr counts half of the unified
 // file) -- nothing spills, and a 64-register wave of the tree kernel can live on every SIMD
-// beside the tower's wave (its block needs 6.5 KB of LDS, the tower leaves 8.8 KB), so when a
+// beside the tower's wave (its block needs 7.5 KB of LDS, the tower leaves 8.8 KB), so when a
 // process runs two contexts on two streams one context's tree round executes under the
 // other's tower instead of waiting for it.
 template <int PR>
