@@ -79,7 +79,7 @@ def main():
                          "in a fixed order, evaluation batch = games x leaves)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the second, informational measurement with two contexts per GPU")
-    ap.add_argument("--full-games", type=float, default=0.0,
+    ap.add_argument("--full-games", type=float, default=40.0,
                     help="after the timed region keep playing for this many seconds and report finished games/hour")
     args = ap.parse_args()
 
@@ -179,13 +179,22 @@ def main():
         el2 = time.perf_counter() - t1
         sts2 = [e.stats() for e in engs]
         st2 = {k: sum(x[k] for x in sts2) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts2) for k in sts2[0]}
-        games_info = {"seconds": el2, "games": st2["games"] - g0, "moves": st2["moves"] - m0,
-                      "games_per_hour": (st2["games"] - g0) / el2 * 3600.0,
-                      "mean_game_length": (st2["moves"] - m0) / max(1, st2["games"] - g0),
+        ng, nm = st2["games"] - g0, st2["moves"] - m0
+        if use_dist:                                       # whole-job totals
+            t = torch.tensor([ng, nm], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ng, nm = int(t[0].item()), int(t[1].item())
+            t = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        games_info = {"seconds": el2, "games": ng, "moves": nm,
+                      "games_per_hour": ng / el2 * 3600.0,
+                      # finished games only: a lower bound on the rate while the first games are still running
+                      "moves_per_s": nm / el2, "mean_game_length": nm / max(1, ng),
                       "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"]}
 
     overlap = None
-    if NC == 1 and not args.no_overlap_probe and G % 2 == 0 and args.full_games <= 0:
+    if NC == 1 and not args.no_overlap_probe and G % 2 == 0:
         # Informational second measurement, never `value`: the same games as two contexts on two streams.
         # A tree block fits on a CU beside a resident tower workgroup, so one context's tree round runs
         # under the other's tower.  Launches of the two contexts overlap in time, which is why the
