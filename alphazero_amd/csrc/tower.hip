@@ -17,6 +17,7 @@
 // consecutive, 256 rows form one output tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "az_tower.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -143,6 +144,11 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
 #define W_BUF_BYTES (128 * 256)  // one tap of weights: 128 rows x 128 k, 16-bit
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) void gl_void;
+// Every LDS-DMA piece this wave has issued has landed (s_waitcnt vmcnt(0); gfx9 encoding: vmcnt in
+// bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima).  Must precede the barrier
+// that hands a weight buffer to the other waves: the compiler orders a wave's own LDS reads after
+// its own DMA, but a barrier alone says nothing about the pieces the OTHER waves are waiting for.
+#define AZ_DMA_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <int PR>
 __global__ void __launch_bounds__(256)
@@ -188,6 +194,7 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
     stage_a(0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) STAGE_W(0, 0, p);
+    AZ_DMA_LANDED();
     __syncthreads();
 
     const int posrow0 = Gd + 64 * wv + l31;            // LDS row of this lane's position, tile j adds 32
@@ -232,6 +239,7 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             }
         }
+        AZ_DMA_LANDED();
         __syncthreads();                               // next tap landed, this one fully read
         if (more && (g + 1) % 9 == 0) {                // next 128-channel slab of the input
             stage_a((g + 1) / 9);
@@ -287,6 +295,173 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
     }
 }
 
+// ReLU, the 16-bit format's saturation and the padding mask in ONE v_med3_f32 per value:
+// cap is Prec::cap() for a real board cell and 0 for a padding row of the raster (whose
+// LDS copy must stay zero: neighbours read it as the convolution's zero padding).
+__device__ __forceinline__ float relu_cap(float x, float cap) { return __builtin_amdgcn_fmed3f(x, 0.f, cap); }
+
+// ------------------------------------------------- conv 3x3, two workgroups per CU
+// The same implicit GEMM on 128-row tiles: 80 KB of LDS and <= 256 registers per wave, so
+// TWO workgroups share a CU and one computes while the other waits for HBM (activation slab,
+// residual tile, output rows) -- the 256-row kernel above leaves the MFMA pipes idle there.
+// grid (M_pad/128, C_pad/128), 256 threads = 4 waves; wave w owns positions [32w, 32w+32) and
+// all 128 output channels: 4 accumulator tiles of 32(ch) x 32(pos).  Weights stream as
+// half-tap chunks [n=128][k=64] (16 KB, taken from the same packed image as above) through a
+// double buffer, buffer-addressed LDS DMA, 16-byte piece c of row n at piece c ^ ((n>>1)&7)
+// (128-byte rows: two rows per bank sweep).
+#define T2_M 128
+#define W2_BYTES (128 * 128)     // half a tap of weights: 128 rows x 64 k, 16-bit
+
+template <int PR>
+__global__ void __launch_bounds__(256, 2)
+az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                       const unsigned short* __restrict__ resid, const unsigned short* __restrict__ wpk,
+                       const float* __restrict__ bias, int C_pad, int M, int N, int Gd, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = N + 1, P = W * W;
+    const int a_rows = T2_M + 2 * Gd;
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * T2_M;
+    const int nb = blockIdx.y;
+    const int n_sc = C_pad / 128;
+    const int total = n_sc * 18;                             // half-tap chunks of this column block
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // weight stream: chunk t = (sc*9 + tap)*2 + half lives in the packed image at
+    // ((nb*n_sc + sc)*9 + tap) * 32 KB, columns [64*half, 64*half + 64) of every row
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(wpk + (size_t)nb * n_sc * 9 * (128 * 128)), 0, n_sc * 9 * (128 * 128 * 2), 0x00020000);
+    // piece q = it*256 + tid of a chunk: LDS row (q >> 3) = it*32 + (tid >> 3), physical piece tid & 7,
+    // logical piece = physical ^ ((row >> 1) & 7) = (tid & 7) ^ ((tid >> 4) & 7) for every it
+    const unsigned st_off = (unsigned)((tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 3)) * 2u;
+    unsigned char* const st_dst = sB + __builtin_amdgcn_readfirstlane(wv) * 1024;
+#define STAGE_W2(t_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+        wrsrc, (lds_void*)(st_dst + ((t_) & 1) * W2_BYTES + (it_) * 4096), 16, st_off, \
+        ((t_) >> 1) * (128 * 128 * 2) + ((t_) & 1) * 128 + (it_) * 8192, 0, 0)
+    auto stage_a = [&](int sc) {
+        for (int r = tid >> 4; r < a_rows; r += 16) {
+            const uint4 v = *(const uint4*)(in + (size_t)(m0 + r) * C_pad + sc * 128 + (tid & 15) * 8);
+            *(uint4*)(sA + r * A_STRIDE + (tid & 15) * 16) = v;
+        }
+    };
+
+#pragma unroll
+    for (int it = 0; it < 4; ++it) STAGE_W2(0, it);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) STAGE_W2(1, it);          // total >= 18: chunk 1 always exists
+    stage_a(0);
+    AZ_DMA_LANDED();
+    __syncthreads();
+
+    const int posrow0 = Gd + 32 * wv + l31;                  // LDS row of this lane's position
+    const int swz = (l31 >> 1) & 7;
+    typename Prec<PR>::vec fx[2], fw[2][4];
+    {
+        const unsigned char* bA = sA + (posrow0 - W - 1) * A_STRIDE + h * 16;
+        const unsigned char* bB = sB + l31 * 128;
+        fx[0] = *(const typename Prec<PR>::vec*)(bA);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 128 + ((h ^ swz) << 4));
+    }
+    for (int t = 0; t < total; ++t) {
+        const int tap = (t >> 1) % 9, hf = t & 1;
+        const int tn_ = t + 1 < total ? t + 1 : t;           // the chunk after this one (the last re-reads itself)
+        const int ntap = (tn_ >> 1) % 9, nhf = tn_ & 1;
+        const bool new_slab = t + 1 < total && (t + 1) % 18 == 0;
+        const unsigned char* bA = sA + (posrow0 + (tap / 3 - 1) * W + (tap % 3 - 1)) * A_STRIDE + hf * 128 + h * 16;
+        const unsigned char* bB = sB + (t & 1) * W2_BYTES + l31 * 128;
+        const unsigned char* nA = sA + (posrow0 + (ntap / 3 - 1) * W + (ntap % 3 - 1)) * A_STRIDE + nhf * 128 + h * 16;
+        const unsigned char* nB = sB + ((t + 1) & 1) * W2_BYTES + l31 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks & 1, n = c ^ 1;
+            const unsigned char* rA = ks < 3 ? bA + (ks + 1) * 32 : nA;
+            const unsigned char* rB = ks < 3 ? bB + ((((ks + 1) * 2 + h) ^ swz) << 4) : nB + ((h ^ swz) << 4);
+            if (ks == 3) {
+                // hand-over: every wave holds its last fragments of this chunk, the next chunk has landed
+                AZ_DMA_LANDED();
+                __syncthreads();
+                // this chunk's buffer is free from here on: start the chunk after next right away, so it
+                // has five k-steps (plus whatever the co-resident workgroup takes) to arrive from L2
+                if (t + 2 < total) { STAGE_W2(t + 2, 0); STAGE_W2(t + 2, 1); STAGE_W2(t + 2, 2); STAGE_W2(t + 2, 3); }
+                if (new_slab) {                              // next 128 input channels: restage the activations
+                    stage_a((t + 1) / 18);
+                    __syncthreads();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#define MF2_(i_) acc[i_] = Prec<PR>::mfma(fw[c][i_], fx[c], acc[i_])
+#define FENCE2_ __builtin_amdgcn_sched_barrier(0)
+            MF2_(0); fx[n] = *(const typename Prec<PR>::vec*)(rA); FENCE2_;
+            MF2_(1); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 128); FENCE2_;
+            MF2_(2); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 128); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 128); FENCE2_;
+            MF2_(3); FENCE2_;
+#undef MF2_
+#undef FENCE2_
+        }
+    }
+#undef STAGE_W2
+    __syncthreads();                                         // all waves done with sA: reuse rows 0..127 for the epilogue
+
+    // epilogue through LDS (this column block's 128 channels of the tile's 128 rows):
+    // coalesced residual load -> + bias (+ residual), ReLU, zero padding rows -> coalesced store
+    if (resid) {
+        for (int i = tid; i < T2_M * 16; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            *(uint4*)(sA + r * A_STRIDE + c * 16) =
+                *(const uint4*)(resid + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8);
+        }
+        __syncthreads();
+    }
+    {
+        const int rr = 32 * wv + l31;
+        const int m = m0 + rr;
+        const int p = m % P;
+        const bool real = m < M && (p / W) < N && (p % W) < N;
+        const unsigned keep = real ? 0xFFFFFFFFu : 0u;
+        const float cap = real ? Prec<PR>::cap() : 0.f;
+        unsigned char* rowp = sA + rr * A_STRIDE + 8 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cch = 32 * i + 8 * q;
+                const float4 bv = *(const float4*)(bias + nb * 128 + cch + 4 * h);
+                float v0 = acc[i][4 * q + 0] + bv.x, v1 = acc[i][4 * q + 1] + bv.y;
+                float v2 = acc[i][4 * q + 2] + bv.z, v3 = acc[i][4 * q + 3] + bv.w;
+                if (resid) {
+                    const uint2 rv = *(const uint2*)(rowp + cch * 2);
+                    v0 += Prec<PR>::from16((unsigned short)(rv.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(rv.x >> 16));
+                    v2 += Prec<PR>::from16((unsigned short)(rv.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(rv.y >> 16));
+                }
+                uint2 o;
+                if (relu) {                                  // ReLU + saturation + padding mask: one v_med3 per value
+                    o.x = Prec<PR>::pack2(relu_cap(v0, cap), relu_cap(v1, cap));
+                    o.y = Prec<PR>::pack2(relu_cap(v2, cap), relu_cap(v3, cap));
+                } else {
+                    o.x = ((unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16)) & keep;
+                    o.y = ((unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16)) & keep;
+                }
+                *(uint2*)(rowp + cch * 2) = o;
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < T2_M * 16; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sA + r * A_STRIDE + c * 16);
+    }
+}
+
 // ------------------------------------------------------------ fused tower
 // The whole tower for one tile of boards in ONE launch (C <= 128, (N+1)^2 <= 256):
 // a workgroup keeps its boards' activations resident in LDS (bf16, zero-padded
@@ -329,11 +504,6 @@ __device__ __forceinline__ void fused_bias_init(AccTile& T, const float* bptr, i
             }
         }
 }
-
-// ReLU, the 16-bit format's saturation and the padding mask in ONE v_med3_f32 per value:
-// cap is Prec::cap() for a real board cell and 0 for a padding row of the raster (whose
-// LDS copy must stay zero: neighbours read it as the convolution's zero padding).
-__device__ __forceinline__ float relu_cap(float x, float cap) { return __builtin_amdgcn_fmed3f(x, 0.f, cap); }
 
 // First convolution of a ResBlock (network.hpp:33): h = relu(Y) goes to LDS as 16-bit
 // activations, and Y restarts from the bias of the next block's first convolution.
@@ -442,7 +612,8 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
             const unsigned char* rB = ks < 7 ? bB + ((((ks + 1) * 2 + h) ^ swz) << 4) : nB + ((h ^ swz) << 4);
             if (ks == 7) {
                 // every wave holds its last fragments of this tap in registers and the next
-                // tap's weights have landed (vmcnt(0)): hand the buffers over
+                // tap's weights have landed: hand the buffers over
+                AZ_DMA_LANDED();
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -606,6 +777,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 #pragma unroll
     for (int p = 0; p < 8; ++p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(st_dst + p * 4096), 16, st_off, p * 4096, 0, 0);
+    AZ_DMA_LANDED();
     __syncthreads();
     TSTAMP(1);
 
@@ -837,6 +1009,7 @@ extern "C" int az_tower_configure(void) {
     hipError_t e = hipSuccess;
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_kernel<0>, 160 * 1024); SETA(az_conv3x3_kernel<1>, 160 * 1024);
+    SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
     SETA(az_tower_fused_kernel<0>, 160 * 1024); SETA(az_tower_fused_kernel<1>, 160 * 1024);
 #undef SETA
@@ -855,8 +1028,16 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
                                   const unsigned short* resid, const unsigned short* wpk, const float* bias,
                                   int C_pad, int M, int N, int Gd, int relu) {
-    const int tiles = (M + TILE_M - 1) / TILE_M;
-    BY_PREC(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
+    static const bool big_tiles = getenv("AZ_CONV_T256") != nullptr;      // the one-workgroup-per-CU variant
+    if (big_tiles) {
+        const int tiles = (M + TILE_M - 1) / TILE_M;
+        BY_PREC(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
+                in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
+        return;
+    }
+    const int tiles = (M + T2_M - 1) / T2_M;
+    const size_t sm = (size_t)(T2_M + 2 * Gd) * A_STRIDE + 2 * W2_BYTES;
+    BY_PREC(az_conv3x3_t128_kernel, dim3(tiles, C_pad / 128), dim3(256), sm, s,
             in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
 }
 
