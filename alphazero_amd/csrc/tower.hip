@@ -313,7 +313,7 @@ __device__ __forceinline__ float relu_cap(float x, float cap) { return __builtin
 #define W2_BYTES (128 * 128)     // half a tap of weights: 128 rows x 64 k, 16-bit
 
 template <int PR>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // LDS allows two workgroups: 256 registers each
 az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
                        const unsigned short* __restrict__ resid, const unsigned short* __restrict__ wpk,
                        const float* __restrict__ bias, int C_pad, int M, int N, int Gd, int relu) {
@@ -348,18 +348,25 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
 #define STAGE_W2(t_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
         wrsrc, (lds_void*)(st_dst + ((t_) & 1) * W2_BYTES + (it_) * 4096), 16, st_off, \
         ((t_) >> 1) * (128 * 128 * 2) + ((t_) & 1) * 128 + (it_) * 8192, 0, 0)
-    auto stage_a = [&](int sc) {
-        for (int r = tid >> 4; r < a_rows; r += 16) {
-            const uint4 v = *(const uint4*)(in + (size_t)(m0 + r) * C_pad + sc * 128 + (tid & 15) * 8);
-            *(uint4*)(sA + r * A_STRIDE + (tid & 15) * 16) = v;
-        }
-    };
+    // activation slab with its halo: all of a thread's loads (<= 11 rows) are in flight together
+    // (a macro, not a lambda: the staging array must stay in registers)
+#define STAGE_A2(sc_) do { \
+        uint4 sv_[11]; \
+        _Pragma("unroll") for (int u = 0; u < 11; ++u) { \
+            const int r_ = min((tid >> 4) + 16 * u, a_rows - 1); \
+            sv_[u] = *(const uint4*)(in + (size_t)(m0 + r_) * C_pad + (sc_) * 128 + (tid & 15) * 8); \
+        } \
+        _Pragma("unroll") for (int u = 0; u < 11; ++u) { \
+            const int r_ = (tid >> 4) + 16 * u; \
+            if (r_ < a_rows) *(uint4*)(sA + r_ * A_STRIDE + (tid & 15) * 16) = sv_[u]; \
+        } \
+    } while (0)
 
 #pragma unroll
     for (int it = 0; it < 4; ++it) STAGE_W2(0, it);
 #pragma unroll
     for (int it = 0; it < 4; ++it) STAGE_W2(1, it);          // total >= 18: chunk 1 always exists
-    stage_a(0);
+    STAGE_A2(0);
     AZ_DMA_LANDED();
     __syncthreads();
 
@@ -395,7 +402,7 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
                 // has five k-steps (plus whatever the co-resident workgroup takes) to arrive from L2
                 if (t + 2 < total) { STAGE_W2(t + 2, 0); STAGE_W2(t + 2, 1); STAGE_W2(t + 2, 2); STAGE_W2(t + 2, 3); }
                 if (new_slab) {                              // next 128 input channels: restage the activations
-                    stage_a((t + 1) / 18);
+                    STAGE_A2((t + 1) / 18);
                     __syncthreads();
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -411,15 +418,22 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
         }
     }
 #undef STAGE_W2
+#undef STAGE_A2
     __syncthreads();                                         // all waves done with sA: reuse rows 0..127 for the epilogue
 
     // epilogue through LDS (this column block's 128 channels of the tile's 128 rows):
     // coalesced residual load -> + bias (+ residual), ReLU, zero padding rows -> coalesced store
     if (resid) {
-        for (int i = tid; i < T2_M * 16; i += 256) {
-            const int r = i >> 4, c = i & 15;
-            *(uint4*)(sA + r * A_STRIDE + c * 16) =
-                *(const uint4*)(resid + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8);
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, c = i & 15;
+            v[u] = *(const uint4*)(resid + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u, r = i >> 4, c = i & 15;
+            *(uint4*)(sA + r * A_STRIDE + c * 16) = v[u];
         }
         __syncthreads();
     }
@@ -1028,7 +1042,7 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
                                   const unsigned short* resid, const unsigned short* wpk, const float* bias,
                                   int C_pad, int M, int N, int Gd, int relu) {
-    static const bool big_tiles = getenv("AZ_CONV_T256") != nullptr;      // the one-workgroup-per-CU variant
+    const bool big_tiles = getenv("AZ_CONV_T256") != nullptr;             // the one-workgroup-per-CU variant (A/B, tests)
     if (big_tiles) {
         const int tiles = (M + TILE_M - 1) / TILE_M;
         BY_PREC(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
