@@ -57,3 +57,50 @@ def save_replay(directory, state, policy, reward):
     save_tensor(np.asarray(state, np.uint8), p + ".state")
     save_tensor(np.asarray(policy, np.float32), p + ".policy")
     save_tensor(np.asarray(reward, np.float32), p + ".reward")
+
+
+class TrainerBuffer:
+    """The trainer-side deque of replay.hpp, to predict what `train` holds after it loaded a
+    `replay/` directory and received rows: rows are (state, policy, reward) tuples.
+
+    The two ways rows enter evict differently:
+      * `receive` (replay.hpp:152-159, one zmq message): append, then signal when the size EQUALS
+        the threshold, then pop the oldest row while size > max_size   -> keeps max_size rows;
+      * `load` (replay.hpp:190-206, rows of the saved tensors): signal BEFORE the append when the
+        size equals the threshold, append, then pop while size >= max_size -> keeps max_size - 1.
+    """
+
+    def __init__(self, max_size=1, threshold=0):
+        self.max_size, self.threshold = int(max_size), int(threshold)
+        self.rows = []
+        self.above_threshold = False
+
+    def receive(self, row):
+        self.rows.append(row)
+        if len(self.rows) == self.threshold:
+            self.above_threshold = True
+        if len(self.rows) > self.max_size:
+            self.rows.pop(0)
+
+    def load(self, rows):
+        for row in rows:
+            if len(self.rows) == self.threshold:
+                self.above_threshold = True
+            self.rows.append(row)
+            if len(self.rows) >= self.max_size:
+                self.rows.pop(0)
+
+    def load_dir(self, directory):
+        got = load_replay(directory)
+        if got is None:
+            return False
+        state, policy, reward = got
+        self.load(list(zip(state, policy, reward)))
+        return True
+
+    def save_dir(self, directory):
+        """replay.hpp:241-274: the three tensors, rows in deque order."""
+        if not self.rows:
+            return
+        save_replay(directory, np.stack([r[0] for r in self.rows]), np.stack([r[1] for r in self.rows]),
+                    np.stack([r[2] for r in self.rows]))

@@ -50,3 +50,27 @@ def test_libtorch_cpp_reads_python_written_files(tmp_path):
     assert [int(x) for x in head.split()] == [5, 3, 1, 2]
     ssum, psum, rsum = tail.split()
     assert int(ssum) == int(s.sum()) and abs(float(psum) - float(p.sum())) < 1e-4 and abs(float(rsum) - 6.0) < 1e-6
+
+
+def test_trainer_buffer_eviction_rules(tmp_path):
+    """replay.hpp:158-159 vs 204-205: a received row evicts at size > max_size, a loaded row at
+    size >= max_size; the threshold flag is raised after the append when receiving and before it
+    when loading."""
+    rows = [(np.full((3, 3, 3), i, np.uint8), np.full((1, 3, 3), i, np.float32), np.array([i, -i], np.float32))
+            for i in range(7)]
+    live = replay_io.TrainerBuffer(max_size=4, threshold=3)
+    for i, r in enumerate(rows):
+        live.receive(r)
+        assert live.above_threshold == (i >= 2)                 # raised by the third row
+    assert [int(r[0][0, 0, 0]) for r in live.rows] == [3, 4, 5, 6]              # keeps max_size rows
+    loaded = replay_io.TrainerBuffer(max_size=4, threshold=3)
+    loaded.load(rows[:3])
+    assert not loaded.above_threshold                           # checked before each append: 0, 1, 2 != 3
+    loaded.load(rows[3:])
+    assert loaded.above_threshold
+    assert [int(r[0][0, 0, 0]) for r in loaded.rows] == [4, 5, 6]               # keeps max_size - 1 rows
+    live.save_dir(str(tmp_path))
+    again = replay_io.TrainerBuffer(max_size=10, threshold=0)
+    assert again.load_dir(str(tmp_path)) and len(again.rows) == 4
+    assert np.array_equal(again.rows[0][2], np.array([3, -3], np.float32))
+    assert not replay_io.TrainerBuffer().load_dir(str(tmp_path / "nothing"))
