@@ -17,10 +17,10 @@
 #define AZ_WAVE 64
 // Optional phase timing (build with -DAZ_TREE_TIMING): block 7 stamps the 100 MHz clock.
 #ifdef AZ_TREE_TIMING
-__device__ unsigned long long az_tree_ts[16];
+__device__ unsigned long long az_tree_ts[32];
 #define TTS(slot_) do { if (blockIdx.x == 7 && threadIdx.x == 0) az_tree_ts[slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int az_tree_timing_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(az_tree_ts), sizeof(unsigned long long) * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(az_tree_ts), sizeof(unsigned long long) * 32);
 }
 #else
 #define TTS(slot_) do {} while (0)
@@ -353,20 +353,41 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     // expanded node has one child per empty cell, so the block size needs no load either
     int fe = 0, ne = A - hl, par_n = uni(d.root_n[g]), player = rt, depth = 0, pend = AZ_PEND_NONE;
     float t0 = 0.f, t1 = 0.f;
+    TTS(10);
     for (;; --ne) {
         const double s = sqrt((double)(par_n - 1));                     // node.hpp:54 sqrt(int) -> double
         float best_val = -100.f;                                        // mcts.hpp:355
         int best_k = -1;
         AzEdge be = {0.f, 0, 0.f, -1};                                  // this lane's best candidate, whole
         int bact = 0;
-        for (int k = threadIdx.x; k < ne; k += AZ_WAVE) {
-            const AzEdge e = E[fe + k];
-            const int act = EA[fe + k];
-            const float q = e.n != 0 ? __fdiv_rn(e.v, (float)e.n) : 0.f;
-            const float cp = cpf * e.p;                                 // int * float -> float
-            const double u = (double)cp * s / (double)(1 + e.n);
-            const float val = (float)((double)q + u);
-            if (val > best_val) { best_val = val; best_k = k; be = e; bact = act; }
+        // four children per lane per trip (a 15x15 node has at most 225 = 3.5 x 64): their loads
+        // are in flight together instead of one L2/HBM round trip per 64 children
+        for (int k0 = threadIdx.x; k0 < ne; k0 += 4 * AZ_WAVE) {
+            AzEdge ce[4];
+            int ca[4];
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int k = min(k0 + u4 * AZ_WAVE, ne - 1);           // clamped: the duplicate never wins (strict >)
+                ce[u4] = E[fe + k];
+                ca[u4] = EA[fe + k];
+            }
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int k = k0 + u4 * AZ_WAVE;
+                const AzEdge e = ce[u4];
+                const float cp = cpf * e.p;                             // int * float -> float
+                float val;
+                if (__ballot(e.n != 0) == 0ull) {
+                    // 64 never-visited children (the common case): q = 0 and the division is by 1.0,
+                    // so q + cp*s/(1+n) is cp*s to the bit -- skip the fp64 divide for the whole wave
+                    val = (float)((double)cp * s);
+                } else {
+                    const float q = e.n != 0 ? __fdiv_rn(e.v, (float)e.n) : 0.f;
+                    const double u = (double)cp * s / (double)(1 + e.n);
+                    val = (float)((double)q + u);
+                }
+                if (k < ne && val > best_val) { best_val = val; best_k = k; be = e; bact = ca[u4]; }
+            }
         }
         int win_k = best_k;
         for (int o = 32; o > 0; o >>= 1) {                              // first maximum in child order
@@ -399,6 +420,7 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         player ^= 1;
         depth++;
         const int child = uni(e.child);
+        if (depth <= 8) TTS(10 + depth);
         if (child >= 0) { fe = child; par_n = uni(e.n); continue; }
         __syncthreads();
         if (child == AZ_CHILD_WAITING) {                                // nothing was stored yet: only the board to undo
@@ -413,6 +435,10 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
             E[pe].v = s_old_v[t] - vl;
             path[t] = pe;
         }
+        TTS(20);
+#ifdef AZ_TREE_TIMING
+        if (threadIdx.x == 0 && blockIdx.x == 7) az_tree_ts[22] = depth;
+#endif
         if (child <= -2) {                                              // stored terminal reward, mcts.hpp:232-233
             pend = AZ_PEND_TERMINAL;
             t0 = child == -2 ? 1.f : (child == -3 ? -1.f : 0.f);
