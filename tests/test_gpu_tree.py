@@ -241,3 +241,39 @@ def test_multi_leaf_selfplay_matches_oracle_games():
     got = {(cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm))}
     missing = [w for w in want if w not in got]
     assert not missing, "%d of %d oracle rows not produced by the device" % (len(missing), len(want))
+
+
+@pytest.mark.parametrize("N,K,budget,L", [(3, 3, 30, 1), (4, 3, 40, 3), (6, 4, 64, 2)])
+def test_selfplay_many_slots_match_oracle(N, K, budget, L):
+    """A wider sweep of the device-side generate loop: 48 slots, three games each, small boards
+    where wins, draws, terminal re-visits, collisions of same-round descents and dropped trees
+    are all frequent.  Every row of every finished game equals the oracle's."""
+    G, games = 48, 3
+    A = N * N
+    seed = 1234 + N
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget, seed=seed, leaves_per_round=L)
+    noise = np.stack([azo.dirichlet(9000 + g, A)[0] for g in range(G)])
+    eng.set_noise(noise)
+    eng.selfplay_begin(budget)
+    got = set()
+    need = (2 * budget + 2 + A * (budget + 1)) * games + 16      # rounds after which every slot has played `games` games
+    done = 0
+    while done < need:                                           # short games finish fast: drain as we go
+        eng.selfplay_run(4 * budget)
+        done += 4 * budget
+        cells, tm, pol, rew = eng.replay_drain(1 << 16)
+        got.update((cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm)))
+    st = eng.stats()
+    assert st["games"] >= games * G and st["error_games"] == 0 and st["replay_dropped"] == 0
+    missing = total = 0
+    for g in range(G):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        m.set_leaves(L)
+        avg, gc, sc = 25.0, 0, 0
+        for _ in range(games):
+            r = m.selfplay_game(budget, seed, g, noise[g], avg, gc, sc)
+            avg, gc, sc = r["avg_len"], r["game_count"], r["sample_counter"]
+            for i in range(r["n_moves"]):
+                total += 1
+                missing += (r["cells"][i].tobytes(), int(r["to_move"][i]), r["policy"][i].tobytes(), r["reward"].tobytes()) not in got
+    assert missing == 0, "%d of %d oracle rows not produced by the device" % (missing, total)
