@@ -9,7 +9,7 @@ TAG=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-overlap-probe > $OUT/trace.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap-probe > $OUT/fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap-probe > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-overlap-probe --full-games 0 > $OUT/trace.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap-probe --full-games 0 > $OUT/fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-overlap-probe --full-games 0 > $OUT/write.log 2>&1
 python3 tools/summarize_profile.py $OUT $TAG
