@@ -16,6 +16,7 @@ AZ_EVAL_TOWER, AZ_EVAL_HASH, AZ_EVAL_EXTERNAL = 0, 1, 2
 AZ_NOISE_EXPLICIT, AZ_NOISE_DEVICE = 0, 1
 AZ_PREC_BF16, AZ_PREC_FP16 = 0, 1
 AZ_MAX_LAYERS = 64
+AZ_OK, AZ_E_ARG, AZ_E_HIP, AZ_E_CAPACITY, AZ_E_STATE, AZ_E_NOWEIGHTS = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [
     "az_last_error", "az_ctx_create", "az_ctx_destroy", "az_sync", "az_stream", "az_weights_size",

@@ -26,6 +26,7 @@ static int fail(int code, const char* fmt, ...) {
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
     return fail(AZ_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 #define AZCHK(call) do { int r_ = (call); if (r_ != AZ_OK) return r_; } while (0)
+#define NEED(ptr) do { if (!(ptr)) return fail(AZ_E_ARG, "null argument: %s", #ptr); } while (0)
 
 extern "C" const char* az_last_error(void) { return g_err.c_str(); }
 
@@ -190,19 +191,23 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         c->C_pad = (c->C + 127) / 128 * 128;
         c->num_res = cfg->n_Cs - 1;
         c->prec = cfg->precision == AZ_PREC_FP16 ? 1 : 0;
-        const size_t M_pad = ((size_t)c->Bmax * c->P + 255) / 256 * 256;
-        c->act_rows = M_pad + 2 * (size_t)c->Gd;
-        AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
-        AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
-        AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27)); AZCHK(dalloc(c, &c->stem_b, c->C_pad));
-        AZCHK(dalloc(c, &c->stem_wbf, (size_t)128 * 32));
-        AZCHK(dalloc(c, &c->conv_wf, (size_t)2 * c->num_res * 9 * 128 * 128));
-        AZCHK(dalloc(c, &c->head_pt, (size_t)258 + 64 * (size_t)A + 64 + 128 + 2));
         c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED");
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
-        AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
+        AZCHK(dalloc(c, &c->stem_b, c->C_pad));
         AZCHK(dalloc(c, &c->conv_b, (size_t)2 * c->num_res * c->C_pad));
-        AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
+        if (c->fused) {                 // whole tower in one launch: activations never leave LDS
+            AZCHK(dalloc(c, &c->stem_wbf, (size_t)128 * 32));
+            AZCHK(dalloc(c, &c->conv_wf, (size_t)2 * c->num_res * 9 * 128 * 128));
+            AZCHK(dalloc(c, &c->head_pt, (size_t)258 + 64 * (size_t)A + 64 + 128 + 2));
+        } else {                        // per-layer path: two activation images in HBM
+            const size_t M_pad = ((size_t)c->Bmax * c->P + 255) / 256 * 256;
+            c->act_rows = M_pad + 2 * (size_t)c->Gd;
+            AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
+            AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
+            AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27));
+            AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
+            AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
+        }
         AZCHK(dalloc(c, &c->tower_in, (size_t)c->Bmax * 3 * A));
         AZCHK(dalloc(c, &c->tower_pol, (size_t)c->Bmax * A)); AZCHK(dalloc(c, &c->tower_val, 2 * (size_t)c->Bmax));
         if (az_tower_configure() != 0) return fail(AZ_E_HIP, "tower kernel LDS configuration failed");
@@ -222,13 +227,14 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     return AZ_OK;
 }
 
-extern "C" int az_tower_is_fused(const az_ctx* c) { return c->fused ? 1 : 0; }
-extern "C" int az_selfplay_batch(const az_ctx* c) { return c->cfg.G * c->d.L; }
-extern "C" int az_sync(az_ctx* c) { return sync_all(c); }
-extern "C" void* az_stream(az_ctx* c) { return (void*)c->stream; }
+extern "C" int az_tower_is_fused(const az_ctx* c) { return c && c->fused ? 1 : 0; }
+extern "C" int az_selfplay_batch(const az_ctx* c) { return c ? c->cfg.G * c->d.L : 0; }
+extern "C" int az_sync(az_ctx* c) { NEED(c); return sync_all(c); }
+extern "C" void* az_stream(az_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // ----------------------------------------------------------------- weights
 extern "C" size_t az_weights_size(const az_ctx* c) {
+    if (!c || c->cfg.eval_mode != AZ_EVAL_TOWER) return 0;
     return weights_size(c->cfg.N, 3, c->cfg.Cs, c->cfg.n_Cs);
 }
 
@@ -264,9 +270,13 @@ static inline unsigned short host_f2h(float x) {
 // BatchNorm (eval, eps 1e-5: network.hpp:13,29-30,71) folded into the preceding
 // convolution in double; 3x3 kernels re-laid as [nb][sc][tap][kc][n][k] chunks.
 extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
+    NEED(c); NEED(blob);
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
     if (n_floats != az_weights_size(c)) return fail(AZ_E_ARG, "blob has %zu floats, expected %zu", n_floats, az_weights_size(c));
     HIPCHK(hipSetDevice(c->cfg.device));
+    // the uploads below are blocking copies that do not order against the context's (non-blocking)
+    // stream: let every launch that still reads the old weights finish first
+    HIPCHK(hipStreamSynchronize(c->stream));
     const int N = c->cfg.N, A = N * N, C = c->C, Cp = c->C_pad, nres = c->num_res;
     auto to16 = [c](float x) { return c->prec == 1 ? host_f2h(x) : host_f2bf(x); };
     const float* p = blob;
@@ -290,7 +300,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
         for (int k = 0; k < 27; ++k) sw[(size_t)co * 27 + k] = (float)(stem.w[(size_t)co * 27 + k] * s);
         sb[co] = (float)(((double)stem.b[co] - stem_bn.rm[co]) * s + stem_bn.b[co]);
     }
-    HIPCHK(hipMemcpy(c->stem_w, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+    if (!c->fused) HIPCHK(hipMemcpy(c->stem_w, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->stem_b, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
     if (c->fused) {
         std::vector<unsigned short> swb((size_t)128 * 32, 0);
@@ -300,15 +310,16 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     }
     // residual convolutions
     const int nblk = Cp / 128;
-    std::vector<unsigned short> pk(c->conv_layer_elems * 2 * nres, 0);
+    std::vector<unsigned short> pk(c->fused ? 0 : c->conv_layer_elems * 2 * nres, 0);
     std::vector<float> cb((size_t)2 * nres * Cp, 0.f);
     for (int L = 0; L < 2 * nres; ++L) {
         const Conv& cv = (L & 1) ? c2[L / 2] : c1[L / 2];
         const Bn& bb = (L & 1) ? b2[L / 2] : b1[L / 2];
-        unsigned short* dst = pk.data() + (size_t)L * c->conv_layer_elems;
+        unsigned short* dst = pk.data() + (c->fused ? 0 : (size_t)L * c->conv_layer_elems);
         for (int co = 0; co < C; ++co) {
             const double s = scale(bb, co);
             cb[(size_t)L * Cp + co] = (float)(((double)cv.b[co] - bb.rm[co]) * s + bb.b[co]);
+            if (c->fused) continue;
             const int nb = co / 128, n = co % 128;
             for (int ci = 0; ci < C; ++ci) {
                 const int sc = ci / 128, k = ci % 128;
@@ -320,7 +331,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
             }
         }
     }
-    HIPCHK(hipMemcpy(c->conv_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    if (!c->fused) HIPCHK(hipMemcpy(c->conv_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     if (c->fused) {                               // one 32 KB chunk per tap: [layer][tap][n][k]
         std::vector<unsigned short> pf((size_t)2 * nres * 9 * 128 * 128, 0);
         for (int L = 0; L < 2 * nres; ++L) {
@@ -348,7 +359,7 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
     memcpy(q, fc1b, sizeof(float) * 64); q += 64;
     memcpy(q, fc2w, sizeof(float) * 128); q += 128;
     memcpy(q, fc2b, sizeof(float) * 2);
-    HIPCHK(hipMemcpy(c->head_p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    if (!c->fused) HIPCHK(hipMemcpy(c->head_p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
     if (c->fused) {
         std::vector<float> ht((size_t)258 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
         for (int ch = 0; ch < C; ++ch) { ht[2 * ch] = hp[ch]; ht[2 * ch + 1] = hp[Cp + ch]; }   // {policy, value} pairs
@@ -366,6 +377,9 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
 }
 
 extern "C" int az_load_weights_dev(az_ctx* c, const float* blob_dev, size_t n_floats) {
+    NEED(c); NEED(blob_dev);
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    if (n_floats != az_weights_size(c)) return fail(AZ_E_ARG, "blob has %zu floats, expected %zu", n_floats, az_weights_size(c));
     std::vector<float> h(n_floats);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipMemcpy(h.data(), blob_dev, n_floats * 4, hipMemcpyDeviceToHost));
@@ -403,12 +417,14 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
 }
 
 extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
+    NEED(c); NEED(boards_dev); NEED(policy_dev); NEED(value_dev);
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
     HIPCHK(hipSetDevice(c->cfg.device));
     return tower_run(c, boards_dev, B, policy_dev, value_dev);
 }
 
 extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* policy, float* value) {
+    NEED(c); NEED(boards); NEED(policy); NEED(value);
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
     if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -423,6 +439,7 @@ extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* 
 
 // --------------------------------------------------------------------- env
 extern "C" int az_env_reset(az_ctx* c) {
+    NEED(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     az_launch_env_reset(c->stream, &c->d);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -430,6 +447,7 @@ extern "C" int az_env_reset(az_ctx* c) {
 }
 
 extern "C" int az_env_step(az_ctx* c, const int32_t* actions, float* reward, uint8_t* done) {
+    NEED(c); NEED(actions); NEED(reward); NEED(done);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
     HIPCHK(hipMemcpyAsync(c->d_actions, actions, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
@@ -445,6 +463,7 @@ extern "C" int az_env_step(az_ctx* c, const int32_t* actions, float* reward, uin
 }
 
 extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
+    NEED(c); NEED(planes);
     HIPCHK(hipSetDevice(c->cfg.device));
     az_launch_env_export(c->stream, &c->d, c->d.leaf_planes, nullptr);
     HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)c->cfg.G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
@@ -453,6 +472,7 @@ extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
 }
 
 extern "C" int az_env_legal_mask(az_ctx* c, uint8_t* mask) {
+    NEED(c); NEED(mask);
     HIPCHK(hipSetDevice(c->cfg.device));
     // borrow the first G*A bytes of the row staging area
     az_launch_env_export(c->stream, &c->d, nullptr, c->d.row_tomove);
@@ -462,8 +482,14 @@ extern "C" int az_env_legal_mask(az_ctx* c, uint8_t* mask) {
 }
 
 extern "C" int az_env_set(az_ctx* c, const uint8_t* cells, const uint8_t* to_move) {
+    NEED(c); NEED(cells); NEED(to_move);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, A = c->A;
+    for (size_t i = 0; i < (size_t)G * A; ++i)
+        if (cells[i] > 2) return fail(AZ_E_ARG, "game %zu: cell value %d (0 empty, 1, 2)", i / A, cells[i]);
+    for (int g = 0; g < G; ++g)
+        if (to_move[g] > 1) return fail(AZ_E_ARG, "game %d: side to move %d (0 or 1)", g, to_move[g]);
+    HIPCHK(hipStreamSynchronize(c->stream));      // blocking copies below do not order against the stream
     // a position set directly has no move history: it is its own history origin
     std::vector<int> zeros(G, 0);
     std::vector<uint8_t> z8(G, 0);
@@ -483,6 +509,7 @@ extern "C" int az_env_set(az_ctx* c, const uint8_t* cells, const uint8_t* to_mov
 // replayed on the host with the same rules, then uploaded with the history so
 // that find() (node.hpp:83-102) can reuse the tree.
 extern "C" int az_env_load(az_ctx* c, const int32_t* hist, const int32_t* hist_len) {
+    NEED(c); NEED(hist); NEED(hist_len);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, A = c->A, N = c->cfg.N;
     std::vector<uint8_t> cells((size_t)G * A, 0), tm(G, 0), over(G, 0);
@@ -513,12 +540,15 @@ extern "C" int az_env_load(az_ctx* c, const int32_t* hist, const int32_t* hist_l
 }
 
 extern "C" int az_set_noise(az_ctx* c, const float* noise) {
+    NEED(c); NEED(noise);
     HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(c->d.noise, noise, (size_t)c->cfg.G * c->A * 4, hipMemcpyHostToDevice));
     return AZ_OK;
 }
 
 extern "C" int az_tree_clear(az_ctx* c) {
+    NEED(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
     {   // keep the arena high-water marks of the trees that are about to be dropped
@@ -568,6 +598,7 @@ static int check_errors(az_ctx* c) {
 }
 
 extern "C" int az_search_begin(az_ctx* c, int budget) {
+    NEED(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     if (c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
         return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget (arena sized for %d nodes)", budget, c->d.node_cap);
@@ -579,6 +610,7 @@ extern "C" int az_search_begin(az_ctx* c, int budget) {
 }
 
 extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
+    NEED(c);
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "external evaluator: use az_search_select/apply");
     AZCHK(az_search_begin(c, budget));
     const int b = budget > 1 ? budget : 1;
@@ -611,6 +643,7 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
 }
 
 extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, int* n_running) {
+    NEED(c); NEED(planes); NEED(pending); NEED(n_running);
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, L = c->d.L;
@@ -631,6 +664,7 @@ extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, in
 }
 
 extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* value) {
+    NEED(c); NEED(policy); NEED(value);
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t S = (size_t)c->cfg.G * c->d.L;
@@ -642,6 +676,7 @@ extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* valu
 }
 
 extern "C" int az_search_result(az_ctx* c, float* out_policy, int32_t* root_n) {
+    NEED(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -659,6 +694,7 @@ extern "C" int az_search_result(az_ctx* c, float* out_policy, int32_t* root_n) {
 extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int32_t* n_nodes, int32_t* n_edges,
                             int32_t* node_first, int32_t* node_count, float* edge_p, int32_t* edge_n,
                             float* edge_v, int32_t* edge_child, int32_t* edge_action) {
+    NEED(c); NEED(n_nodes); NEED(n_edges);
     if (game < 0 || game >= c->cfg.G) return fail(AZ_E_ARG, "game %d out of range", game);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -671,6 +707,7 @@ extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int
     *n_nodes = nn; *n_edges = ne;
     if (node_cap == 0 && edge_cap == 0) return AZ_OK;
     if (node_cap < nn || edge_cap < ne) return fail(AZ_E_ARG, "dump buffers too small (%d nodes, %d edges)", nn, ne);
+    NEED(node_first); NEED(node_count); NEED(edge_p); NEED(edge_n); NEED(edge_v); NEED(edge_child); NEED(edge_action);
     std::vector<AzEdge> ed(ne);
     std::vector<uint16_t> ea(ne);
     HIPCHK(hipMemcpy(ed.data(), c->d.edges[ar] + (size_t)game * c->d.edge_cap, sizeof(AzEdge) * ne, hipMemcpyDeviceToHost));
@@ -699,6 +736,7 @@ extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int
 
 // --------------------------------------------------------------- self-play
 extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
+    NEED(c);
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "self-play needs a device evaluator");
     HIPCHK(hipSetDevice(c->cfg.device));
     if (c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
@@ -719,6 +757,7 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
 }
 
 extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
+    NEED(c);
     if (c->mode != AZ_MODE_SELFPLAY) return fail(AZ_E_STATE, "az_selfplay_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     for (int r = 0; r < rounds; ++r) {
@@ -733,6 +772,9 @@ extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
 }
 
 extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    NEED(c);
+    if (cap < 0) return fail(AZ_E_ARG, "cap %d is negative", cap);
+    if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     unsigned long long cnt = 0;
@@ -745,12 +787,17 @@ extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_m
         HIPCHK(hipMemcpy(policy, c->d.ring_policy, (size_t)n * A * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(reward, c->d.ring_reward, (size_t)n * 2 * 4, hipMemcpyDeviceToHost));
     }
-    if ((unsigned long long)n < cnt) {        // keep the tail: shift it to the front
+    if (n > 0 && (unsigned long long)n < cnt) {
+        // keep the tail: shift it to the front, n rows at a time from the low end so that the source
+        // and destination of one copy never overlap
         const size_t rest = (size_t)(cnt - n);
-        HIPCHK(hipMemcpy(c->d.ring_cells, c->d.ring_cells + (size_t)n * A, rest * A, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(c->d.ring_tomove, c->d.ring_tomove + n, rest, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(c->d.ring_policy, c->d.ring_policy + (size_t)n * A, rest * A * 4, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(c->d.ring_reward, c->d.ring_reward + (size_t)n * 2, rest * 8, hipMemcpyDeviceToDevice));
+        for (size_t off = 0; off < rest; off += (size_t)n) {
+            const size_t k = std::min<size_t>((size_t)n, rest - off);
+            HIPCHK(hipMemcpy(c->d.ring_cells + off * A, c->d.ring_cells + (off + n) * A, k * A, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(c->d.ring_tomove + off, c->d.ring_tomove + off + n, k, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(c->d.ring_policy + off * A, c->d.ring_policy + (off + n) * A, k * A * 4, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(c->d.ring_reward + off * 2, c->d.ring_reward + (off + n) * 2, k * 8, hipMemcpyDeviceToDevice));
+        }
     }
     cnt -= n;
     HIPCHK(hipMemcpy(c->d.counters + 4, &cnt, 8, hipMemcpyHostToDevice));
@@ -758,6 +805,7 @@ extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_m
 }
 
 extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
+    NEED(c); NEED(s);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     const int G = c->cfg.G;
@@ -791,6 +839,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
 
 // ---------------------------------------------------------------- profiling
 extern "C" int az_profile_enable(az_ctx* c, int every) {
+    NEED(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->prof_every = every;
@@ -798,14 +847,19 @@ extern "C" int az_profile_enable(az_ctx* c, int every) {
     c->prof_used = 0;
     c->prof_spans.clear();
     if (every > 0 && c->prof_pool.empty()) {
-        c->prof_pool.resize(8192);
-        for (auto& e : c->prof_pool) HIPCHK(hipEventCreate(&e));
+        c->prof_pool.reserve(8192);
+        for (int i = 0; i < 8192; ++i) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            c->prof_pool.push_back(e);
+        }
     }
     return AZ_OK;
 }
 
 extern "C" int az_profile_read(az_ctx* c, double* conv_avg_us, int64_t* conv_launches,
                                double* tree_avg_us, int64_t* tree_launches) {
+    NEED(c); NEED(conv_avg_us); NEED(conv_launches); NEED(tree_avg_us); NEED(tree_launches);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     double sum[2] = {0, 0};

@@ -109,3 +109,36 @@ def test_search_is_deterministic_across_contexts_and_slots():
         eng.close()
     assert np.array_equal(outs[0], outs[1])
     assert all(np.array_equal(outs[0][0], outs[0][g]) for g in range(G))
+
+
+def test_replay_drain_in_small_pieces_keeps_row_order():
+    """Draining with a buffer smaller than the ring's content hands the rows over in the same
+    order as one big drain (the rows that stay are moved to the front on the device)."""
+    N, K, G, budget = 3, 3, 8, 12
+
+    def play():
+        eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget, seed=11)
+        eng.selfplay_begin(budget)
+        eng.selfplay_run(300)
+        return eng
+
+    whole = play().replay_drain()
+    assert len(whole[0]) > 40
+    eng = play()
+    parts = []
+    for cap in (3, 1, 7, 2, 1 << 16):
+        parts.append(eng.replay_drain(cap))
+    assert len(parts[0][0]) == 3 and len(parts[2][0]) == 7
+    for i in range(4):
+        assert np.array_equal(np.concatenate([p[i] for p in parts]), whole[i])
+    assert len(eng.replay_drain()[0]) == 0
+
+
+def test_null_arguments_are_refused_not_dereferenced():
+    lib = capi.load()
+    assert lib.az_sync(None) == capi.AZ_E_ARG
+    assert lib.az_get_stats(None, None) == capi.AZ_E_ARG
+    assert lib.az_selfplay_batch(None) == 0
+    eng = capi.Engine(3, 3, 1, eval_mode=capi.AZ_EVAL_HASH, max_budget=8)
+    assert lib.az_env_step(eng.h, None, None, None) == capi.AZ_E_ARG
+    assert b"null argument" in lib.az_last_error()
