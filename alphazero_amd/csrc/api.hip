@@ -174,7 +174,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     d.ring_cap = std::max(4 * G * A / 2, 4096);
     DA(ring_cells, (size_t)d.ring_cap * A); DA(ring_tomove, d.ring_cap);
     DA(ring_policy, (size_t)d.ring_cap * A); DA(ring_reward, 2 * (size_t)d.ring_cap);
-    DA(counters, 16); DA(g_evals, G); DA(g_hw_nodes, G); DA(g_hw_edges, G);
+    DA(counters, 16); DA(g_ctr, (size_t)G * AZ_GC_STRIDE); DA(g_hw_nodes, G); DA(g_hw_edges, G);
 #undef DA
     HIPCHK(hipMemset(d.root_hist_len, 0xFF, sizeof(int) * G));      // -1: no tree
     {   // uniform noise default so an unset buffer is still a distribution
@@ -744,7 +744,7 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     c->d.budget = budget > 1 ? budget : 1;
     c->mode = AZ_MODE_SELFPLAY;
     HIPCHK(hipMemsetAsync(c->d.counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    HIPCHK(hipMemsetAsync(c->d.g_evals, 0, sizeof(unsigned long long) * c->cfg.G, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.g_ctr, 0, sizeof(unsigned long long) * AZ_GC_STRIDE * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.g_hw_nodes, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.g_hw_edges, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.err, 0, sizeof(int) * c->cfg.G, c->stream));
@@ -812,7 +812,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     unsigned long long k[16];
     HIPCHK(hipMemcpy(k, c->d.counters, sizeof k, hipMemcpyDeviceToHost));
     std::vector<int> err(G), st(G), sd(G), nn(G), ne(G), hn(G), he(G);
-    std::vector<unsigned long long> ev(G);
+    std::vector<unsigned long long> gc((size_t)G * AZ_GC_STRIDE);
     HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * G, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(st.data(), c->d.status, sizeof(int) * G, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(sd.data(), c->d.sims_done, sizeof(int) * G, hipMemcpyDeviceToHost));
@@ -820,7 +820,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     HIPCHK(hipMemcpy(ne.data(), c->d.n_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hn.data(), c->d.g_hw_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(he.data(), c->d.g_hw_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ev.data(), c->d.g_evals, sizeof(unsigned long long) * G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gc.data(), c->d.g_ctr, sizeof(unsigned long long) * gc.size(), hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
     s->sims = (int64_t)k[0]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
     s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
@@ -828,7 +828,10 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     // simulations backed up = those of completed searches + the progress of searches in flight
     s->sims_backed_up = (int64_t)k[0];
     for (int g = 0; g < G; ++g) {
-        s->evals += (int64_t)ev[g];
+        const unsigned long long* q = gc.data() + (size_t)g * AZ_GC_STRIDE;
+        s->evals += (int64_t)q[AZ_GC_EVALS]; s->descents += (int64_t)q[AZ_GC_DESCENTS];
+        s->tree_levels += (int64_t)q[AZ_GC_LEVELS]; s->children_scanned += (int64_t)q[AZ_GC_SCANNED];
+        s->children_expanded += (int64_t)q[AZ_GC_EXPANDED];
         if (st[g] == AZ_ST_RUN) s->sims_backed_up += sd[g];
         s->max_nodes = std::max(s->max_nodes, std::max(hn[g], nn[g]));
         s->max_edges = std::max(s->max_edges, std::max(he[g], ne[g]));

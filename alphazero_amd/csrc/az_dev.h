@@ -25,6 +25,8 @@ enum { AZ_ST_IDLE = 0, AZ_ST_RUN = 1 };
 enum { AZ_MODE_SEARCH = 0, AZ_MODE_SELFPLAY = 1 };
 
 // All per-game state, structure-of-arrays over the G games of one GPU.
+enum { AZ_GC_EVALS = 0, AZ_GC_DESCENTS = 1, AZ_GC_LEVELS = 2, AZ_GC_SCANNED = 3, AZ_GC_EXPANDED = 4, AZ_GC_STRIDE = 8 };
+
 struct AzTreeDev {
     int G, N, A, K;
     int L;                      // leaves (descents) per tree per round; evaluation slot = g*L + k
@@ -91,7 +93,10 @@ struct AzTreeDev {
     // counters touched at most once per move: [0] sims of completed searches [2] moves [3] games
     // [4] ring rows [5] dropped.  Everything counted per round lives per game (no hot shared word):
     unsigned long long* counters;
-    unsigned long long* g_evals;        // [G] boards submitted to the evaluator
+    unsigned long long* g_ctr;          // [G][AZ_GC_STRIDE] per-game tallies (one 64-byte line per game, no shared hot word):
+                                        //   AZ_GC_EVALS boards submitted to the evaluator, AZ_GC_DESCENTS descents that stood,
+                                        //   AZ_GC_LEVELS tree levels they walked, AZ_GC_SCANNED child edges they read,
+                                        //   AZ_GC_EXPANDED child edges written by expansions
     int*      g_hw_nodes;       // [G] arena high-water marks, noted when a tree shrinks
     int*      g_hw_edges;       // [G]
 };

@@ -286,6 +286,7 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         if (threadIdx.x == 0) {
             d.n_nodes[g] = nn + 1;
             d.n_edges[g] = ne0 + base;
+            d.g_ctr[(size_t)g * AZ_GC_STRIDE + AZ_GC_EXPANDED] += (unsigned long long)base;
             if (!is_root) E[path[plen - 1]].child = ne0;                // leaf->add (mcts.hpp:316): link = its block's first edge
         }
         __syncthreads();
@@ -333,7 +334,7 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     const int hl = uni(d.hist_len[g]);
     if (uni(d.root_hist_len[g]) < 0) {                                  // fresh root: evaluate the root board
         az_write_planes(d, slot, s_cells, rt);
-        if (threadIdx.x == 0) { d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; d.g_evals[g] = d.g_evals[g] + 1ull; }
+        if (threadIdx.x == 0) { d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; d.g_ctr[(size_t)g * AZ_GC_STRIDE + AZ_GC_EVALS] += 1ull; }
         return 1;
     }
     // per-ply records of this descent, all in LDS: while descending the wave issues loads only;
@@ -352,6 +353,7 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     // a node is its block of child edges: the root's starts at edge 0, a child's at edge.child; an
     // expanded node has one child per empty cell, so the block size needs no load either
     int fe = 0, ne = A - hl, par_n = uni(d.root_n[g]), player = rt, depth = 0, pend = AZ_PEND_NONE;
+    int scanned = 0;                                                    // child edges read by this descent
     float t0 = 0.f, t1 = 0.f;
     TTS(10);
     for (;; --ne) {
@@ -419,6 +421,7 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         const int mover = player;
         player ^= 1;
         depth++;
+        scanned += ne;
         const int child = uni(e.child);
         if (depth <= 8) TTS(10 + depth);
         if (child >= 0) { fe = child; par_n = uni(e.n); continue; }
@@ -465,7 +468,9 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         d.pending[slot] = pend;
         d.path_len[slot] = depth;
         if (pend == AZ_PEND_TERMINAL) { d.pend_result[2 * slot] = t0; d.pend_result[2 * slot + 1] = t1; }
-        else d.g_evals[g] = d.g_evals[g] + 1ull;                        // per game: no hot shared counter in the round
+        unsigned long long* gc = d.g_ctr + (size_t)g * AZ_GC_STRIDE;    // per game: no hot shared counter in the round
+        if (pend != AZ_PEND_TERMINAL) gc[AZ_GC_EVALS] += 1ull;
+        gc[AZ_GC_DESCENTS] += 1ull; gc[AZ_GC_LEVELS] += (unsigned long long)depth; gc[AZ_GC_SCANNED] += (unsigned long long)scanned;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < depth; t += AZ_WAVE) s_cells[s_act[t]] = 0;

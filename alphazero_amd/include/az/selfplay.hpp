@@ -101,6 +101,8 @@ public:
             t.sims += s.sims; t.evals += s.evals; t.moves += s.moves; t.games += s.games;
             t.replay_rows += s.replay_rows; t.replay_dropped += s.replay_dropped;
             t.error_games += s.error_games; t.sims_backed_up += s.sims_backed_up;
+            t.descents += s.descents; t.tree_levels += s.tree_levels;
+            t.children_scanned += s.children_scanned; t.children_expanded += s.children_expanded;
             t.rounds = s.rounds > t.rounds ? s.rounds : t.rounds;
             t.max_nodes = s.max_nodes > t.max_nodes ? s.max_nodes : t.max_nodes;
             t.max_edges = s.max_edges > t.max_edges ? s.max_edges : t.max_edges;

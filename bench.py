@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak of one MI355X
+HBM_PEAK_GBS = 8000.0                # HBM3E peak of one MI355X
 
 
 def cpu_baseline(seconds, N, K, budget, nthreads):
@@ -144,7 +145,10 @@ def main():
     run(args.warmup)
     eng.profile_enable(8)
     barrier()
-    sims0 = sum(e.stats()["sims_backed_up"] for e in engs)
+    TALLY = ("descents", "tree_levels", "children_scanned", "children_expanded", "evals")
+    st0 = [e.stats() for e in engs]
+    sims0 = sum(x["sims_backed_up"] for x in st0)
+    tally0 = {k: sum(x[k] for x in st0) for k in TALLY}
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
@@ -158,6 +162,7 @@ def main():
     sts = [e.stats() for e in engs]
     st = {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
     sims_local = st["sims_backed_up"] - sims0              # simulations this rank backed up inside the timed region
+    tally = {k: st[k] - tally0[k] for k in TALLY}          # what this rank's tree kernel walked, read and wrote
     if use_dist:
         t = torch.tensor([sims_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -264,6 +269,27 @@ def main():
                          "flops_per_launch": conv_flops,
                          "tree_round_avg_us": prof["tree_avg_us"]},
         }
+        # Tree kernel against the HBM roofline: algorithmic bytes = 12 B (p, n, v) per child edge read at
+        # every level of every descent + 24 B per level (virtual-loss write + backup read-modify-write) +
+        # 16 B per child edge written by an expansion + per evaluated leaf its planes (3A B) out and its
+        # policy and value (4A + 8 B) in; counted on the device (az_stats), rank 0's games, per launch.
+        if tally["descents"] > 0 and prof["tree_avg_us"] > 0:
+            tree_bytes = (12.0 * tally["children_scanned"] + 24.0 * tally["tree_levels"] + 16.0 * tally["children_expanded"]
+                          + tally["evals"] * (7.0 * A + 8.0)) / args.steps / NC
+            tree_traffic = None
+            if traffic is not None:
+                try:
+                    tree_traffic = json.load(open(tj))["kernels"]["az_round_kernel"]["traffic_bytes_per_launch"]
+                except Exception:  # noqa: BLE001
+                    tree_traffic = None
+            gbs = tree_bytes / (prof["tree_avg_us"] * 1e-6) / 1e9
+            line["tree_roofline"] = {
+                "bound": "hbm", "kernel": "az_round_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": tree_traffic, "avg_launch_us": prof["tree_avg_us"],
+                "launches_sampled": prof["tree_launches"], "bytes_per_launch": tree_bytes,
+                "mean_depth": tally["tree_levels"] / tally["descents"],
+                "mean_children_per_level": tally["children_scanned"] / max(1, tally["tree_levels"]),
+                "note": "a chain of dependent loads, one per tree level: latency-bound, 512 one-wave blocks"}
         line["full_games"] = games_info
         line["two_context_overlap"] = overlap
         if world == 1 and not args.no_cpu_baseline:

@@ -84,6 +84,12 @@ typedef struct az_stats {
     int32_t error_games;          /* games whose arena overflowed */
     int32_t reserved;
     int64_t sims_backed_up;       /* simulations backed up so far, searches in flight included */
+    /* what the tree kernel's memory traffic is made of (summed over games since the context's
+     * creation or its last az_selfplay_begin): */
+    int64_t descents;             /* root-to-leaf descents that stood (__select_and_eval, mcts.hpp:211-237) */
+    int64_t tree_levels;          /* tree levels those descents walked (sum of path lengths) */
+    int64_t children_scanned;     /* child edges read by __choose (mcts.hpp:350-381) on the way */
+    int64_t children_expanded;    /* child edges written by _append_children (mcts.hpp:425-455) */
 } az_stats;
 
 const char* az_last_error(void);
