@@ -99,11 +99,17 @@ def test_per_layer_path_matches_fused_path(monkeypatch, big_tiles):
     assert np.abs(p1 - p2).max() < TOL and np.abs(v1 - v2).max() < TOL
 
 
-def test_wide_tower_256_channels_matches_torch():
-    """BASELINE config 5 shape class: 256-channel blocks (per-layer path)."""
+@pytest.mark.parametrize("kernel", ["w256", "t128"])
+@pytest.mark.parametrize("N,B", [(9, 6), (15, 5), (19, 3)])
+def test_wide_tower_256_channels_matches_torch(monkeypatch, kernel, N, B):
+    """BASELINE config 5 shape class: 256-channel blocks (per-layer path), on the 256-row x
+    256-channel kernel (the default for widths that are multiples of 256) and on the 128-row
+    kernel; batches whose last tile is partial and whose tiles straddle boards."""
     import torch
     torch.set_num_threads(8)
-    N, B, Cs = 9, 6, [256, 256, 256]
+    if kernel == "t128":
+        monkeypatch.setenv("AZ_CONV_T128", "1")
+    Cs = [256, 256, 256]
     blob = synth.make_blob(N, 3, Cs, 31)
     boards = synth.random_boards(B, N, seed=31)
     eng = capi.Engine(N, 5, B, Cs=Cs)
@@ -113,6 +119,31 @@ def test_wide_tower_256_channels_matches_torch():
     with torch.no_grad():
         rp, rv = torch_reference(N, Cs, blob, boards)
     assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
+
+
+def test_wide_tower_many_tiles_per_workgroup_matches_128_row_kernel(monkeypatch):
+    """The 256 x 256 kernel is persistent (one workgroup per CU walks tiles x, x + 256, ...): a batch of
+    more than 256 tiles runs every workgroup through several tiles and the last ones through a ragged
+    count.  Checked against the 128-row kernel on the same weights (same operand rounding, different
+    summation order) and, for a sample of boards, against torch fp32."""
+    import torch
+    torch.set_num_threads(8)
+    N, B, Cs = 9, 1400, [256, 256, 256]                 # 1400 boards x 100 raster rows = 547 tiles of 256 rows
+    blob = synth.make_blob(N, 3, Cs, 41)
+    boards = synth.random_boards(B, N, seed=41)
+    eng = capi.Engine(N, 5, B, Cs=Cs)
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(boards)
+    eng.close()
+    monkeypatch.setenv("AZ_CONV_T128", "1")
+    eng2 = capi.Engine(N, 5, B, Cs=Cs)
+    eng2.load_weights(blob)
+    pol2, val2 = eng2.tower_forward(boards)
+    assert np.abs(pol - pol2).max() < 1e-4 and np.abs(val - val2).max() < 1e-3
+    pick = np.r_[0:8, 636:644, B - 8:B]                 # first tiles, a workgroup's second tile, the ragged end
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, boards[pick])
+    assert np.abs(pol[pick] - rp).max() < TOL and np.abs(val[pick] - rv).max() < TOL
 
 
 def test_tower_requires_weights_and_uniform_widths():
