@@ -267,6 +267,10 @@ def main():
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
                          "flops_per_launch": conv_flops,
+                         # informational: a bare MFMA loop at the issue floor reaches this on random bf16 operands
+                         # (the chip lowers its clock under MFMA load; tools/microbench/mfma_power.hip); `peak` and
+                         # `frac` stay priced against the datasheet's dense peak
+                         "bare_mfma_loop_on_random_data_tflops": 1830.0,
                          "tree_round_avg_us": prof["tree_avg_us"]},
         }
         # Tree kernel against the HBM roofline: algorithmic bytes = 12 B (p, n, v) per child edge read at
