@@ -694,14 +694,10 @@ az_conv3x3_w256_kernel(const unsigned short* __restrict__ in, unsigned short* ou
             if (ks == 3) {
                 // hand-over: every wave holds its last fragments of this chunk, the next chunk (and, at a
                 // slice boundary, the next slab) has landed
-#ifndef W3_NO_BARRIER
                 AZ_DMA_LANDED();
                 __syncthreads();
-#endif
-#ifndef W3_NO_DMA
                 // the other slab buffer was last read by the previous slice: free after this barrier
                 if (tap == 0 && kc + 1 < n_kc) STAGE_A3(arsrc, kc + 1);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #define MF3_(i_, j_) acc[i_][j_] = Prec<PR>::mfma(fw[c][i_], fx[c][j_], acc[i_][j_])
@@ -711,11 +707,7 @@ az_conv3x3_w256_kernel(const unsigned short* __restrict__ in, unsigned short* ou
             // this chunk's weight buffer is free after the hand-over: the chunk after next goes into it, one
             // 1 KB piece per wave after every second MFMA (a burst of eight stalls the wave on the memory
             // pipeline's issue queue for ~60 cycles a piece)
-#ifndef W3_NO_DMA
 #define DMA3_(it_) do { if (ks == 3 && t + 2 < total) STAGE_W3(t + 2, it_); } while (0)
-#else
-#define DMA3_(it_) do {} while (0)
-#endif
             MF3_(0, 0); LDX3_(0); FENCE3_; MF3_(1, 0); LDW3_(0); DMA3_(0); FENCE3_;
             MF3_(2, 0); LDX3_(1); FENCE3_; MF3_(3, 0); LDW3_(1); DMA3_(1); FENCE3_;
             MF3_(0, 1); LDX3_(2); FENCE3_; MF3_(1, 1); LDW3_(2); DMA3_(2); FENCE3_;
