@@ -62,3 +62,37 @@ def test_host_rules_match_oracle_on_random_playouts():
                     break
             # an occupied cell is rejected by both
             assert capi.host_env_step(N, K, cb, tb, a)[3] < 0 and azo.env_step(N, K, ca, ta, a)[3] < 0
+
+
+def test_ctypes_structures_match_the_header_layout(tmp_path):
+    """alphazero_amd/capi.py restates az_config and az_stats by hand: compile a probe against
+    include/az_hip.h with the C compiler and compare sizes and every field offset."""
+    import ctypes
+    import subprocess
+    fields = {"az_config": [f for f, _ in capi.AzConfig._fields_], "az_stats": [f for f, _ in capi.AzStats._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "az_hip.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fs:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    src.append('return 0; }')
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("az_config", capi.AzConfig), ("az_stats", capi.AzStats)):
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for f in fields[st]:
+            assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
+
+
+def test_null_context_is_refused_without_a_gpu():
+    """Argument checks come before any HIP call."""
+    lib = capi.load()
+    assert lib.az_sync(None) == capi.AZ_E_ARG
+    assert lib.az_selfplay_run(None, 1) == capi.AZ_E_ARG
+    assert lib.az_weights_size(None) == 0
+    assert lib.az_ctx_create(None, None) == capi.AZ_E_ARG
+    assert b"null argument" in lib.az_last_error()
+    assert lib.az_ctx_destroy(None) == capi.AZ_OK
