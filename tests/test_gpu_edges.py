@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import azo
-from alphazero_amd import capi
+from alphazero_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -171,3 +171,33 @@ def test_traffic_tallies_follow_from_the_tree(L):
     assert st["tree_levels"] == levels
     assert st["children_scanned"] == scanned
     assert st["children_expanded"] == expanded
+
+
+def test_largest_board_and_longest_line():
+    """N = 21 is the largest board the context accepts (N*N <= 448 path entries), K = 8 the longest
+    winning line: tree parity against the oracle, tower parity against torch on the per-layer path."""
+    import torch
+    from test_gpu_tower import TOL, torch_reference
+    N, K, G, budget = 21, 8, 2, 90
+    eng, noise = _fresh(N, K, G, budget)
+    eng.env_load([[220, 221, 199], []])
+    out = eng.search(budget)
+    for g, hist in enumerate([[220, 221, 199], []]):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        assert np.array_equal(out[g], m.search(hist, budget, noise[g]))
+        assert eng.tree_canonical(g) == azo.canonical_tree(m.dump())
+    with pytest.raises(capi.AzError, match="unsupported"):
+        capi.Engine(22, 5, 1, eval_mode=capi.AZ_EVAL_HASH, max_budget=8)
+    with pytest.raises(capi.AzError, match="win length"):
+        capi.Engine(9, 9, 1, eval_mode=capi.AZ_EVAL_HASH, max_budget=8)
+    torch.set_num_threads(8)
+    Cs = synth.NETCONFIG2
+    blob = synth.make_blob(N, 3, Cs, 5)
+    boards = synth.random_boards(3, N, seed=5)
+    te = capi.Engine(N, K, 4, Cs=Cs)
+    assert not te.tower_is_fused()
+    te.load_weights(blob)
+    pol, val = te.tower_forward(boards)
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, boards)
+    assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
