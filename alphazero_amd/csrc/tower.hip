@@ -5,10 +5,11 @@
 //                     launch, activations resident in LDS (C <= 128, (N+1)^2 <= 256)
 //   az_stem_kernel    ConvBlock (network.hpp:15-17): 3x3 conv on the u8 planes,
 //                     BN folded, ReLU; fp32 VALU                       } per-layer
-//   az_conv3x3_kernel ResBlock convolutions (network.hpp:32-38) as      } path for
-//                     implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}:  } wider or
-//                     D[ch][pos] = sum_k W[ch][k] X[k][pos]             } larger
-//   az_heads_kernel   PolicyHead + ValueHead (network.hpp:51-60,75-83)  } shapes
+//   az_conv3x3_t128_kernel, az_conv3x3_w256_kernel                      } path for
+//                     ResBlock convolutions (network.hpp:32-38) as      } wider or
+//                     implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}:  } larger
+//                     D[ch][pos] = sum_k W[ch][k] X[k][pos]             } shapes
+//   az_heads_kernel   PolicyHead + ValueHead (network.hpp:51-60,75-83)  }
 //
 // Activation layout in HBM: bf16 rows [guard + M_pad + guard][C_pad]; one row
 // per board position in a zero-padded (N+1)x(N+1) raster (column N and row N
@@ -130,170 +131,15 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
 }
 
 // ---------------------------------------------------------------- conv 3x3
-// Per-layer implicit GEMM (any C multiple of 128, any N <= 21): used where the
-// fused kernel does not apply (C = 256, or boards larger than one tile).
-// grid (M_pad/256, C_pad/128), 256 threads = 4 waves; wave w owns positions
-// [64w, 64w+64) of the tile and all 128 output channels of the column block:
-// 4x2 accumulator tiles of 32(ch) x 32(pos).
-// Weights are pre-packed as 32 KB chunks [nb][sc][tap][n=128][k=128] (BN scale
-// folded) and copied global -> LDS by global_load_lds into a double buffer whose
-// image is XOR-swizzled through the source address (16-byte piece c of row n at
-// piece c ^ (n & 15)).  The activation tile with its halo is staged once per
-// 128-channel slab and reused by all 9 taps; the output goes back through LDS so
-// that HBM sees whole 256-byte rows.
+// Per-layer implicit GEMMs (any C multiple of 128, any N <= 21): used where the fused kernel does not
+// apply (C = 256, or boards larger than one tile).  Shared pieces first.
 #define W_BUF_BYTES (128 * 256)  // one tap of weights: 128 rows x 128 k, 16-bit
 typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) void gl_void;
 // Every LDS-DMA piece this wave has issued has landed (s_waitcnt vmcnt(0); gfx9 encoding: vmcnt in
 // bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima).  Must precede the barrier
 // that hands a weight buffer to the other waves: the compiler orders a wave's own LDS reads after
 // its own DMA, but a barrier alone says nothing about the pieces the OTHER waves are waiting for.
 #define AZ_DMA_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
-
-template <int PR>
-__global__ void __launch_bounds__(256)
-az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
-                  const unsigned short* __restrict__ resid, const unsigned short* __restrict__ wpk,
-                  const float* __restrict__ bias, int C_pad, int M, int N, int Gd, int relu) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int W = N + 1, P = W * W;
-    const int a_rows = TILE_M + 2 * Gd;
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * TILE_M;
-    const int nb = blockIdx.y;
-    const int n_sc = C_pad / 128;
-    const int total = n_sc * 9;
-    const unsigned short* wbase = wpk + (size_t)nb * n_sc * 9 * (128 * 128);
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int st_row = tid >> 4;
-    const int st_src = st_row * 128 + (((tid & 15) ^ (st_row & 15)) << 3);
-    unsigned char* const st_dst = sB + (tid & ~63) * 16;
-#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_global_load_lds( \
-        (gl_void*)(wbase + (size_t)(g_) * (128 * 128) + (p_) * (16 * 128) + st_src), \
-        (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, 0, 0)
-    auto stage_a = [&](int sc) {
-        for (int r = tid >> 4; r < a_rows; r += 16) {
-            const uint4 v = *(const uint4*)(in + (size_t)(m0 + r) * C_pad + sc * 128 + (tid & 15) * 8);
-            *(uint4*)(sA + r * A_STRIDE + (tid & 15) * 16) = v;
-        }
-    };
-
-    stage_a(0);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) STAGE_W(0, 0, p);
-    AZ_DMA_LANDED();
-    __syncthreads();
-
-    const int posrow0 = Gd + 64 * wv + l31;            // LDS row of this lane's position, tile j adds 32
-    const int swz = l31 & 15;
-    for (int g = 0; g < total; ++g) {
-        const int tap = g % 9;
-        const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
-        const bool more = g + 1 < total;
-        const unsigned char* bA = sA + (posrow0 + toff) * A_STRIDE + h * 16;
-        const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
-        typename Prec<PR>::vec fx[2][2], fw[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (more && ks < 4) { STAGE_W(g + 1, (g + 1) & 1, 2 * ks); STAGE_W(g + 1, (g + 1) & 1, 2 * ks + 1); }
-            if (ks < 7) {
-                const int wo = (((ks + 1) * 2 + h) ^ swz) << 4;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fx[(ks + 1) & 1][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE + (ks + 1) * 32);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fw[(ks + 1) & 1][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + wo);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = Prec<PR>::mfma(fw[ks & 1][i], fx[ks & 1][j], acc[i][j]);
-            if (ks < 7) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            }
-        }
-        AZ_DMA_LANDED();
-        __syncthreads();                               // next tap landed, this one fully read
-        if (more && (g + 1) % 9 == 0) {                // next 128-channel slab of the input
-            stage_a((g + 1) / 9);
-            __syncthreads();
-        }
-    }
-#undef STAGE_W
-
-    // epilogue through LDS (rows 0..255 of sA, this column block's 128 channels):
-    // coalesced residual load -> + bias (+ residual), ReLU, zero padding rows -> coalesced store
-    if (resid) {
-        for (int i = tid; i < TILE_M * 16; i += 256) {
-            const int r = i >> 4, c = i & 15;
-            *(uint4*)(sA + r * A_STRIDE + c * 16) =
-                *(const uint4*)(resid + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rr = 64 * wv + 32 * j + l31;
-        const int m = m0 + rr;
-        const int p = m % P;
-        const unsigned keep = (m < M && (p / W) < N && (p % W) < N) ? 0xFFFFFFFFu : 0u;
-        unsigned char* rowp = sA + rr * A_STRIDE + 8 * h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cch = 32 * i + 8 * q;
-                const float4 bv = *(const float4*)(bias + nb * 128 + cch + 4 * h);
-                float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
-                float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
-                if (resid) {
-                    const uint2 rv = *(const uint2*)(rowp + cch * 2);
-                    v0 += Prec<PR>::from16((unsigned short)(rv.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(rv.x >> 16));
-                    v2 += Prec<PR>::from16((unsigned short)(rv.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(rv.y >> 16));
-                }
-                uint2 o;
-                if (relu) { o.x = Prec<PR>::pack2_relu(v0, v1); o.y = Prec<PR>::pack2_relu(v2, v3); }
-                else {
-                    o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
-                    o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
-                }
-                o.x &= keep; o.y &= keep;
-                *(uint2*)(rowp + cch * 2) = o;
-            }
-    }
-    __syncthreads();
-    for (int i = tid; i < TILE_M * 16; i += 256) {
-        const int r = i >> 4, c = i & 15;
-        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sA + r * A_STRIDE + c * 16);
-    }
-}
 
 // ReLU, the 16-bit format's saturation and the padding mask in ONE v_med3_f32 per value:
 // cap is Prec::cap() for a real board cell and 0 for a padding row of the raster (whose
@@ -301,14 +147,16 @@ az_conv3x3_kernel(const unsigned short* __restrict__ in, unsigned short* __restr
 __device__ __forceinline__ float relu_cap(float x, float cap) { return __builtin_amdgcn_fmed3f(x, 0.f, cap); }
 
 // ------------------------------------------------- conv 3x3, two workgroups per CU
-// The same implicit GEMM on 128-row tiles: 80 KB of LDS and <= 256 registers per wave, so
-// TWO workgroups share a CU and one computes while the other waits for HBM (activation slab,
-// residual tile, output rows) -- the 256-row kernel above leaves the MFMA pipes idle there.
+// Implicit GEMM on 128-row tiles: 80 KB of LDS and <= 256 registers per wave, so TWO workgroups
+// share a CU and one computes while the other waits for HBM (activation slab, residual tile,
+// output rows).
 // grid (M_pad/128, C_pad/128), 256 threads = 4 waves; wave w owns positions [32w, 32w+32) and
-// all 128 output channels: 4 accumulator tiles of 32(ch) x 32(pos).  Weights stream as
-// half-tap chunks [n=128][k=64] (16 KB, taken from the same packed image as above) through a
-// double buffer, buffer-addressed LDS DMA, 16-byte piece c of row n at piece c ^ ((n>>1)&7)
-// (128-byte rows: two rows per bank sweep).
+// all 128 output channels: 4 accumulator tiles of 32(ch) x 32(pos).  The activation tile with its
+// halo is staged once per 128-channel slab and reused by all 9 taps.  Weights are pre-packed as
+// [nb][sc][tap][n=128][k=128] images (BN scale folded) and stream as half-tap chunks [n=128][k=64]
+// (16 KB) through a double buffer by buffer-addressed LDS DMA, 16-byte piece c of row n at piece
+// c ^ ((n>>1)&7) (128-byte rows: two rows per bank sweep), applied through the source address.
+// The output goes back through LDS so that HBM sees whole 256-byte rows.
 #define T2_M 128
 #define W2_BYTES (128 * 128)     // half a tap of weights: 128 rows x 64 k, 16-bit
 
@@ -1288,12 +1136,10 @@ az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------ host launchers
-static inline size_t conv_smem(int Gd) { return (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES; }
 
 extern "C" int az_tower_configure(void) {
     hipError_t e = hipSuccess;
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
-    SETA(az_conv3x3_kernel<0>, 160 * 1024); SETA(az_conv3x3_kernel<1>, 160 * 1024);
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_w256_kernel<0>, 160 * 1024); SETA(az_conv3x3_w256_kernel<1>, 160 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
@@ -1314,20 +1160,13 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
                                   const unsigned short* resid, const unsigned short* wpk, const unsigned short* wpk256,
                                   const float* bias, int C_pad, int M, int N, int Gd, int relu) {
-    const bool big_tiles = getenv("AZ_CONV_T256") != nullptr;             // the one-workgroup-per-CU variant (A/B, tests)
-    if (wpk256 && C_pad % 256 == 0 && !big_tiles && !getenv("AZ_CONV_T128")) {   // 256 rows x 256 channels per workgroup
+    if (wpk256 && C_pad % 256 == 0 && !getenv("AZ_CONV_T128")) {          // 256 rows x 256 channels per workgroup
         const int tiles = (M + T3_M - 1) / T3_M;
         const size_t sm = 2 * (size_t)W3_BYTES + 2 * (size_t)t3_slab_rows(Gd) * 128 + 1024;
         const int col_blocks = C_pad / 256;
         const int wgs = tiles < 256 / col_blocks ? tiles : (256 / col_blocks > 0 ? 256 / col_blocks : 1);   // persistent: one workgroup per CU
         BY_PREC(az_conv3x3_w256_kernel, dim3(wgs, col_blocks), dim3(256), sm, s,
                 in, out, resid, wpk256, bias, C_pad, M, tiles, N, Gd, relu);
-        return;
-    }
-    if (big_tiles) {
-        const int tiles = (M + TILE_M - 1) / TILE_M;
-        BY_PREC(az_conv3x3_kernel, dim3(tiles, C_pad / 128), dim3(256), conv_smem(Gd), s,
-                in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
         return;
     }
     const int tiles = (M + T2_M - 1) / T2_M;

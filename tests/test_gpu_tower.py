@@ -77,13 +77,9 @@ def test_tower_matches_torch_fp32(N, B, prec):
     assert np.abs(pol2 - rp[:2]).max() < TOL and np.abs(val2 - rv[:2]).max() < TOL
 
 
-@pytest.mark.parametrize("big_tiles", [False, True], ids=["t128x2", "t256x1"])
-def test_per_layer_path_matches_fused_path(monkeypatch, big_tiles):
-    """The per-convolution kernels (used for C > 128 or N > 15) against the
-    fused kernel on a shape both can run: the default 128-row tiles with two
-    workgroups per CU, and the 256-row one-workgroup variant."""
-    if big_tiles:
-        monkeypatch.setenv("AZ_CONV_T256", "1")
+def test_per_layer_path_matches_fused_path(monkeypatch):
+    """The per-convolution kernel (used for N > 15, and for C > 128 when the width is not a
+    multiple of 256) against the fused kernel on a shape both can run."""
     N, B, Cs = 15, 9, synth.NETCONFIG2
     blob = synth.make_blob(N, 3, Cs, 21)
     boards = synth.random_boards(B, N, seed=21)
