@@ -82,7 +82,18 @@ def main():
                     help="skip the second, informational measurement with two contexts per GPU")
     ap.add_argument("--full-games", type=float, default=40.0,
                     help="after the timed region keep playing for this many seconds and report finished games/hour")
+    ap.add_argument("--config", type=int, choices=[1, 2, 4], default=None,
+                    help="preset of BASELINE.json configs[i]: 1 = 9x9, 256 games, 400 sims/move; 2 = the default "
+                         "(15x15, 512 games per GPU, 800 sims/move); 4 = tower only, 20 blocks x 256 channels, "
+                         "batch 8192 (runs tools/tower_bench.py, single GPU)")
     args = ap.parse_args()
+    if args.config == 1:
+        args.board, args.games, args.budget = 9, 256, 400
+    elif args.config == 4:
+        sys.argv = [os.path.join(ROOT, "tools", "tower_bench.py"), "--precision", args.precision]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import tower_bench
+        return tower_bench.main()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
