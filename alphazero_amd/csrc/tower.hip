@@ -616,19 +616,21 @@ extern "C" int az_tower_timing_read(unsigned long long* out) {
 #define TSTAMP(slot_) do {} while (0)
 #endif
 
-// Accumulator tile of one wave in the MFMA C/D layout: 128 channels x 64 positions.
-// T[i][j][4q+c] = channel 32i + 8q + 4h + c, position 32j + l31 of the wave's 64 rows.
-typedef f32x16 AccTile[4][2];
+// Accumulator tile of one wave in the MFMA C/D layout: 128 channels x 32 J positions (J = 2: 256-row
+// workgroup tiles; J = 1: 128-row tiles for small boards, so that a small batch still fills the chip).
+// T[i][j][4q+c] = channel 32i + 8q + 4h + c, position 32j + l31 of the wave's 32 J rows.
+template <int J> using AccTile = f32x16[4][J];
 
 // T = bias[channel], broadcast over positions (the convolution then accumulates on top).
-__device__ __forceinline__ void fused_bias_init(AccTile& T, const float* bptr, int h) {
+template <int J>
+__device__ __forceinline__ void fused_bias_init(AccTile<J>& T, const float* bptr, int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bv = *(const float4*)(bptr + 32 * i + 8 * q + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < J; ++j) {
                 T[i][j][4 * q + 0] = bv.x; T[i][j][4 * q + 1] = bv.y;
                 T[i][j][4 * q + 2] = bv.z; T[i][j][4 * q + 3] = bv.w;
             }
@@ -637,17 +639,17 @@ __device__ __forceinline__ void fused_bias_init(AccTile& T, const float* bptr, i
 
 // First convolution of a ResBlock (network.hpp:33): h = relu(Y) goes to LDS as 16-bit
 // activations, and Y restarts from the bias of the next block's first convolution.
-template <int PR>
-__device__ __forceinline__ void fused_epi_hidden(AccTile& Y, const float* next_bias, unsigned char* row0,
-                                                 float cap0, float cap1, int h) {
+template <int PR, int J>
+__device__ __forceinline__ void fused_epi_hidden(AccTile<J>& Y, const float* next_bias, unsigned char* row0,
+                                                 const float (&caps)[J], int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bv = *(const float4*)(next_bias + 32 * i + 8 * q + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float cap = j ? cap1 : cap0;
+            for (int j = 0; j < J; ++j) {
+                const float cap = caps[j];
                 uint2 o;
                 o.x = Prec<PR>::pack2(relu_cap(Y[i][j][4 * q + 0], cap), relu_cap(Y[i][j][4 * q + 1], cap));
                 o.y = Prec<PR>::pack2(relu_cap(Y[i][j][4 * q + 2], cap), relu_cap(Y[i][j][4 * q + 3], cap));
@@ -665,17 +667,17 @@ __device__ __forceinline__ void fused_epi_hidden(AccTile& Y, const float* next_b
 // the new fp32 residual and, rounded to 16 bits, the next layer's input in LDS; X then
 // takes the bias of the next block's second convolution on top of the residual.  The
 // residual of a padding row is held at zero too (it only ever feeds itself).
-template <int PR>
-__device__ __forceinline__ void fused_epi_residual(AccTile& X, const float* next_bias, unsigned char* row0,
-                                                   float cap0, float cap1, int h) {
+template <int PR, int J>
+__device__ __forceinline__ void fused_epi_residual(AccTile<J>& X, const float* next_bias, unsigned char* row0,
+                                                   const float (&caps)[J], int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bv = *(const float4*)(next_bias + 32 * i + 8 * q + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float cap = j ? cap1 : cap0;
+            for (int j = 0; j < J; ++j) {
+                const float cap = caps[j];
                 const float r0 = relu_cap(X[i][j][4 * q + 0], cap), r1 = relu_cap(X[i][j][4 * q + 1], cap);
                 const float r2 = relu_cap(X[i][j][4 * q + 2], cap), r3 = relu_cap(X[i][j][4 * q + 3], cap);
                 uint2 o;
@@ -696,8 +698,8 @@ __device__ __forceinline__ void fused_epi_residual(AccTile& X, const float* next
 // (global_load_lds, 16 B per lane, no staging registers).  The LDS image is lane-linear,
 // so the bank-conflict fix is an XOR swizzle applied to the SOURCE address and again on
 // the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
-template <int PR>
-__device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
+template <int PR, int J>
+__device__ __forceinline__ void fused_conv_taps(AccTile<J>& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
                                                 __amdgpu_buffer_rsrc_t wrsrc, unsigned st_off, unsigned char* st_dst,
                                                 int posrow0, int W, int h, int l31) {
     const int swz = l31 & 15;
@@ -712,11 +714,11 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
     // the LDS latency), and the pipeline runs across tap boundaries: the barrier that
     // hands over the weight buffers sits before the LAST k-step of a tap, whose MFMAs
     // then cover the first fragment reads of the next tap.
-    typename Prec<PR>::vec fx[2][2], fw[2][4];
+    typename Prec<PR>::vec fx[2][J], fw[2][4];
     const unsigned char* bA = sA + (posrow0 - W - 1) * A_STRIDE + h * 16;          // tap 0: (-1,-1)
     const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
+    for (int j = 0; j < J; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
 #pragma unroll
     for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
     for (int tap = 0; tap < 9; ++tap, ++g) {
@@ -749,16 +751,26 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
             }
 #define MF_(i_, j_) acc[i_][j_] = Prec<PR>::mfma(fw[c][i_], fx[c][j_], acc[i_][j_])
 #define FENCE_ __builtin_amdgcn_sched_barrier(0)
-            MF_(0, 0); fx[n][0] = *(const typename Prec<PR>::vec*)(rA); FENCE_;
-            MF_(0, 1); fx[n][1] = *(const typename Prec<PR>::vec*)(rA + 32 * A_STRIDE); FENCE_;
-            MF_(1, 0); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); FENCE_;
-            MF_(1, 1); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 256); FENCE_;
-            MF_(2, 0); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 256); FENCE_;
-            MF_(2, 1); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 256); FENCE_;
-            MF_(3, 0);
-            if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
-            FENCE_;
-            MF_(3, 1); FENCE_;
+            if constexpr (J == 2) {
+                MF_(0, 0); fx[n][0] = *(const typename Prec<PR>::vec*)(rA); FENCE_;
+                MF_(0, 1); fx[n][1] = *(const typename Prec<PR>::vec*)(rA + 32 * A_STRIDE); FENCE_;
+                MF_(1, 0); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); FENCE_;
+                MF_(1, 1); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 256); FENCE_;
+                MF_(2, 0); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 256); FENCE_;
+                MF_(2, 1); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 256); FENCE_;
+                MF_(3, 0);
+                if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
+                FENCE_;
+                MF_(3, 1); FENCE_;
+            } else {
+                // 128-row tiles: 4 MFMAs per k-step on one activation and four weight fragments
+                MF_(0, 0); fx[n][0] = *(const typename Prec<PR>::vec*)(rA); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); FENCE_;
+                MF_(1, 0); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 256); FENCE_;
+                MF_(2, 0); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 256); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 256); FENCE_;
+                MF_(3, 0);
+                if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
+                FENCE_;
+            }
 #undef MF_
 #undef FENCE_
         }
@@ -775,7 +787,7 @@ __device__ __forceinline__ void fused_conv_taps(AccTile& acc, int g, int total, 
 #ifndef AZ_TOWER_REG_CAP
 #define AZ_TOWER_REG_CAP __attribute__((amdgpu_num_vgpr(224)))
 #endif
-template <int PR>
+template <int PR, int J>
 __global__ void __launch_bounds__(256) AZ_TOWER_REG_CAP
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
@@ -783,12 +795,14 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                       float* __restrict__ policy, float* __restrict__ value,
                       int B, int N, int Gd, int n_layers, int bpt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TM = 128 * J;                              // rows of the workgroup's tile
+    constexpr int PW = 32 * J;                               // positions per wave
     const int W = N + 1, P = W * W, A = N * N;
-    const int a_rows = TILE_M + 2 * Gd;
+    const int a_rows = TM + 2 * Gd;
     unsigned char* sA = smem;
     unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
-    unsigned char* sI = sB;                                  // stem im2col [256][I_STRIDE]
-    unsigned char* sW = sB + TILE_M * I_STRIDE;              // stem weights [128][I_STRIDE]
+    unsigned char* sI = sB;                                  // stem im2col [TM][I_STRIDE]
+    unsigned char* sW = sB + TM * I_STRIDE;                  // stem weights [128][I_STRIDE]
     float* sBias = (float*)(sB + 2 * W_BUF_BYTES);           // [n_layers + 1][128]: stem bias, then every conv's
     uint8_t* sP = (uint8_t*)(sBias + (n_layers + 1) * 128);  // planes of this tile's boards
 
@@ -821,7 +835,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         ((float4*)sBias)[i] = i < 32 ? ((const float4*)stem_b)[i] : ((const float4*)bias)[i - 32];
     for (int i = tid; i < 2 * Gd * (A_STRIDE / 16); i += 256) {
         const int r = i / (A_STRIDE / 16), c = i % (A_STRIDE / 16);
-        *(uint4*)(sA + (size_t)(r < Gd ? r : r + TILE_M) * A_STRIDE + c * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(sA + (size_t)(r < Gd ? r : r + TM) * A_STRIDE + c * 16) = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) if (tid + 256 * t < np) sP[tid + 256 * t] = pl[t];
@@ -832,7 +846,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     }
     __syncthreads();
     TSTAMP(40);
-    {   // im2col row of tile position `tid`: k = ci*9 + ky*3 + kx, bf16(u8) is exact
+    if (tid < TM) {   // im2col row of tile position `tid`: k = ci*9 + ky*3 + kx, bf16(u8) is exact
         unsigned short v[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) v[k] = 0;
@@ -863,14 +877,14 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();
     TSTAMP(41);
 
-    AccTile X, Y;        // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
+    AccTile<J> X, Y;     // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
     fused_bias_init(X, sBias, h);                            // stem bias
 
-    // which of this lane's two positions are real board cells
-    float keepcap[2];
+    // which of this lane's positions are real board cells
+    float keepcap[J];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 64 * wv + 32 * j + l31;
+    for (int j = 0; j < J; ++j) {
+        const int r = PW * wv + 32 * j + l31;
         const int p = r % P;
         keepcap[j] = (r < rows_here && (p / W) < N && (p % W) < N) ? Prec<PR>::cap() : 0.f;
     }
@@ -878,22 +892,22 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     // stem: 2 k-steps of 16 over the im2col tile
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        typename Prec<PR>::vec xb[2], wa[4];
+        typename Prec<PR>::vec xb[J], wa[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xb[j] = *(const typename Prec<PR>::vec*)(sI + (64 * wv + 32 * j + l31) * I_STRIDE + ks * 32 + h * 16);
+        for (int j = 0; j < J; ++j) xb[j] = *(const typename Prec<PR>::vec*)(sI + (PW * wv + 32 * j + l31) * I_STRIDE + ks * 32 + h * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) wa[i] = *(const typename Prec<PR>::vec*)(sW + (32 * i + l31) * I_STRIDE + ks * 32 + h * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < J; ++j)
                 X[i][j] = Prec<PR>::mfma(wa[i], xb[j], X[i][j]);
     }
     __syncthreads();                                         // every wave is done with sI / sW
     TSTAMP(42);
     // bias table: [0] stem, [1 + L] convolution L.  Block b = convolutions 2b (onto Y) and 2b+1 (onto X).
-    unsigned char* const row0 = sA + (size_t)(Gd + 64 * wv + l31) * A_STRIDE + 8 * h;
-    fused_epi_residual<PR>(X, sBias + 2 * 128, row0, keepcap[0], keepcap[1], h);
+    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + l31) * A_STRIDE + 8 * h;
+    fused_epi_residual<PR, J>(X, sBias + 2 * 128, row0, keepcap, h);
     fused_bias_init(Y, sBias + 1 * 128, h);
 
     // weight stream set-up (see fused_conv_taps): piece p (0..7) of a chunk is 256 lanes x 16 B;
@@ -914,19 +928,19 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();
     TSTAMP(1);
 
-    const int posrow0 = Gd + 64 * wv + l31;
+    const int posrow0 = Gd + PW * wv + l31;
     const int n_blocks = n_layers >> 1;
     for (int b = 0; b < n_blocks; ++b) {
         const int nb1 = min(3 + 2 * b, n_layers), nb2 = min(4 + 2 * b, n_layers);     // next block's biases
-        fused_conv_taps<PR>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
+        fused_conv_taps<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         // (the barrier before the last k-step: all waves have finished reading this layer's input)
         TSTAMP(2 + 4 * b);
-        fused_epi_hidden<PR>(Y, sBias + nb1 * 128, row0, keepcap[0], keepcap[1], h);
+        fused_epi_hidden<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, h);
         __syncthreads();
         TSTAMP(3 + 4 * b);
-        fused_conv_taps<PR>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
+        fused_conv_taps<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         TSTAMP(4 + 4 * b);
-        fused_epi_residual<PR>(X, sBias + nb2 * 128, row0, keepcap[0], keepcap[1], h);
+        fused_epi_residual<PR, J>(X, sBias + nb2 * 128, row0, keepcap, h);
         __syncthreads();
         TSTAMP(5 + 4 * b);
     }
@@ -1143,7 +1157,8 @@ extern "C" int az_tower_configure(void) {
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_w256_kernel<0>, 160 * 1024); SETA(az_conv3x3_w256_kernel<1>, 160 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
-    SETA(az_tower_fused_kernel<0>, 160 * 1024); SETA(az_tower_fused_kernel<1>, 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 1>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1>), 160 * 1024);
 #undef SETA
     return (int)e;
 }
@@ -1179,12 +1194,28 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
                                       const float* stem_b, const unsigned short* wpk, const float* bias,
                                       const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers) {
     const int P = (N + 1) * (N + 1);
-    const int bpt = TILE_M / P;
+    // Tile height: 256 rows (two 32-position blocks per wave), or 128 rows where a whole board fits in 128
+    // and the batch is too small to fill the chip with 256-row tiles.  A 128-row tile does half the MFMA
+    // work per weight byte, so it costs ~0.6 of a 256-row tile, not 0.5: take it when it saves tile rounds.
+    int rows = TILE_M;
+    const char* force = getenv("AZ_FUSED_ROWS");             // "128" / "256": A/B and tests
+    if (P <= 128) {
+        const int t256 = (B + TILE_M / P - 1) / (TILE_M / P), t128 = (B + 128 / P - 1) / (128 / P);
+        const int r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;      // rounds of one tile per CU
+        if (3 * r128 < 5 * r256) rows = 128;
+        if (force) rows = atoi(force) == 128 ? 128 : TILE_M;
+    }
+    const int bpt = rows / P;
     const int tiles = (B + bpt - 1) / bpt;
-    const size_t sm = (size_t)(TILE_M + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)(n_layers + 1) * 128 * 4 +
+    const size_t sm = (size_t)(rows + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)(n_layers + 1) * 128 * 4 +
                       (size_t)bpt * 3 * N * N + 16;
-    BY_PREC(az_tower_fused_kernel, dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias,
-            hp, policy, value, B, N, Gd, n_layers, bpt);
+    if (rows == 128) {
+        if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, 1>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
+        else hipLaunchKernelGGL((az_tower_fused_kernel<0, 1>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
+    } else {
+        if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, 2>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
+        else hipLaunchKernelGGL((az_tower_fused_kernel<0, 2>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
+    }
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,

@@ -77,6 +77,28 @@ def test_tower_matches_torch_fp32(N, B, prec):
     assert np.abs(pol2 - rp[:2]).max() < TOL and np.abs(val2 - rv[:2]).max() < TOL
 
 
+@pytest.mark.parametrize("rows", ["128", "256"])
+@pytest.mark.parametrize("N,B", [(9, 300), (3, 70), (10, 5), (5, 33)])
+def test_fused_tile_heights_match_torch(monkeypatch, rows, N, B):
+    """Boards of at most 128 raster positions run in 128-row tiles when that saves tile rounds;
+    both heights forced here, on batches with ragged last tiles and several boards per tile."""
+    import torch
+    torch.set_num_threads(8)
+    monkeypatch.setenv("AZ_FUSED_ROWS", rows)
+    Cs = synth.NETCONFIG2
+    blob = synth.make_blob(N, 3, Cs, 51 + N)
+    boards = synth.random_boards(B, N, seed=50 + N)
+    eng = capi.Engine(N, min(N, 5), B, Cs=Cs)
+    assert eng.tower_is_fused()
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(boards)
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, boards)
+    assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
+    pol2, val2 = eng.tower_forward(boards[:3])
+    assert np.array_equal(pol2, pol[:3]) and np.array_equal(val2, val[:3])
+
+
 def test_per_layer_path_matches_fused_path(monkeypatch):
     """The per-convolution kernel (used for N > 15, and for C > 128 when the width is not a
     multiple of 256) against the fused kernel on a shape both can run."""
