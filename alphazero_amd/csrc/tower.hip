@@ -5,7 +5,7 @@
 //                     launch, activations resident in LDS (C <= 128, (N+1)^2 <= 256)
 //   az_stem_kernel    ConvBlock (network.hpp:15-17): 3x3 conv on the u8 planes,
 //                     BN folded, ReLU; fp32 VALU                       } per-layer
-//   az_conv3x3_t128_kernel, az_conv3x3_w256_kernel                      } path for
+//   az_conv3x3_t256_kernel, az_conv3x3_w256_kernel, az_conv3x3_t128_kernel } path for
 //                     ResBlock convolutions (network.hpp:32-38) as      } wider or
 //                     implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}:  } larger
 //                     D[ch][pos] = sum_k W[ch][k] X[k][pos]             } shapes
@@ -321,6 +321,210 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
     for (int i = tid; i < T2_M * 16; i += 256) {
         const int r = i >> 4, c = i & 15;
         *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sA + r * A_STRIDE + c * 16);
+    }
+}
+
+// ------------------------------------- conv 3x3, 256 rows x 128 channels, two workgroups per CU
+// For boards larger than one LDS tile (N > 15) and widths that are not multiples of 256.  The 128-row
+// kernel above asks L2 for a weight byte per 128 rows (32 B/clk per CU with two workgroups resident:
+// at the limit of what a CU gets from L2); this one keeps the two-workgroups-per-CU overlap (72 KB of
+// LDS, 256 registers) but covers 256 rows per weight byte: wave w owns positions [64w, 64w+64) and all
+// 128 output channels of the column block (4 x 2 accumulator tiles, 8 MFMAs per k-step on 4 weight + 2
+// activation fragments).  The reduction runs over 64-channel input slices x 9 taps: per (slice, tap) one
+// 16 KB weight chunk [n=128][k=64] through a double buffer (same packed image and source-address swizzle
+// as the 128-row kernel), per slice one activation slab [256 + 2 Gd rows][64 ch] in a SINGLE buffer,
+// by buffer-addressed LDS DMA with piece c of row r at c ^ ((r >> 1) & 7).  Re-loading the slab between
+// slices stalls this workgroup; the co-resident one computes meanwhile.  Epilogue through a swizzled
+// 256-byte-pitch image (piece c of row r at c ^ (r & 15)): residual rows in by LDS DMA, arithmetic in
+// place, whole rows out.
+#define T4_M 256
+static inline __host__ __device__ int t4_slab_rows(int Gd) { return (T4_M + 2 * Gd + 7) / 8 * 8; }
+
+template <int PR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* out,
+                       const unsigned short* resid /* may alias out */, const unsigned short* __restrict__ wpk,
+                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Prec<PR>::vec vec;
+    const int W = N + 1, P = W * W;
+    const int rows_total = n_tiles * T4_M + 2 * Gd;          // rows of the activation buffers
+    const int slab_rows = t4_slab_rows(Gd);
+    unsigned char* sW = smem;                                // 2 x W2_BYTES
+    unsigned char* sA = smem + 2 * W2_BYTES;                 // slab_rows x 128 B; the epilogue image (64 KB) starts at smem
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * T4_M;
+    const int nb = blockIdx.y;
+    const int n_sc = C_pad / 128;
+    const int n_kc = C_pad / 64;
+    const int total = n_kc * 9;                              // (slice, tap) chunks
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // weights: chunk t = kc*9 + tap lives in the packed image at ((nb*n_sc + kc/2)*9 + tap) * 32 KB, columns
+    // [64*(kc&1), +64) of every 256-byte row; piece q = it*256 + tid of a chunk: LDS row it*32 + (tid >> 3),
+    // physical piece tid & 7 = logical piece ^ ((row >> 1) & 7)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(wpk + (size_t)nb * n_sc * 9 * (128 * 128)), 0, n_sc * 9 * (128 * 128 * 2), 0x00020000);
+    const unsigned w_voff = (unsigned)((tid >> 3) * 256 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4));
+    unsigned char* const w_dst = sW + wvu * 1024;
+#define CHUNK_SRC4(t_) ((((t_) / 9 >> 1) * 9 + (t_) % 9) * (128 * 128 * 2) + (((t_) / 9) & 1) * 128)
+#define STAGE_W4(t_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+        wrsrc, (lds_void*)(w_dst + ((t_) & 1) * W2_BYTES + (it_) * 4096), 16, w_voff, CHUNK_SRC4(t_) + (it_) * 8192, 0, 0)
+    // slab: DMA q covers rows 8q .. 8q+7 (lane: row 8q + (lane >> 3), physical piece lane & 7); wave w issues
+    // q = w, w+4, ..., so (row >> 1) & 7 = 4 (w & 1) + (lane >> 4) is a per-lane constant
+    const size_t a_left = (size_t)(rows_total - m0) * C_pad * 2;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(in + (size_t)m0 * C_pad), 0, (int)(a_left < 0x7FFFFFFFull ? a_left : 0x7FFFFFFFull), 0x00020000);
+    const unsigned a_voff = (unsigned)((lane >> 3) * C_pad * 2 + (((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7)) << 4));
+    const int n_q = slab_rows / 8;
+#define STAGE_A4(kc_) do { \
+        for (int q_ = wvu; q_ < n_q; q_ += 4) \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sA + q_ * 1024), 16, \
+                                                     a_voff, q_ * 8 * C_pad * 2 + (kc_) * 128, 0, 0); \
+    } while (0)
+
+#pragma unroll
+    for (int it = 0; it < 4; ++it) STAGE_W4(0, it);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) STAGE_W4(1, it);          // total >= 18: chunk 1 always exists
+    STAGE_A4(0);
+    AZ_DMA_LANDED();
+    __syncthreads();
+
+    const int s_base = Gd + 64 * wv + l31;                   // slab row of this lane's first position
+    const int swzW = (l31 >> 1) & 7;
+    const unsigned char* const wrow = sW + l31 * 128;
+    vec fx[2][2], fw[2][4];
+    {
+        const int s0 = s_base - W - 1;                       // tap 0
+        const int sz = (s0 >> 1) & 7;
+        const unsigned char* bX = sA + s0 * 128 + ((h ^ sz) << 4);
+        const unsigned char* bW = wrow + ((h ^ swzW) << 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fx[0][j] = *(const vec*)(bX + j * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[0][i] = *(const vec*)(bW + i * 4096);
+    }
+    for (int t = 0; t < total; ++t) {
+        const int kc = t / 9, tap = t - 9 * kc;
+        const int tn_ = t + 1 < total ? t + 1 : t;
+        const int ntap = tn_ - 9 * (tn_ / 9);
+        const int s0 = s_base + (tap / 3 - 1) * W + (tap % 3 - 1);
+        const int ns0 = s_base + (ntap / 3 - 1) * W + (ntap % 3 - 1);
+        const int sz = (s0 >> 1) & 7, nsz = (ns0 >> 1) & 7;
+        const unsigned char* bX = sA + s0 * 128;
+        const unsigned char* nX = sA + ns0 * 128;
+        const unsigned char* bW = wrow + (t & 1) * W2_BYTES;
+        const unsigned char* nW = wrow + ((t + 1) & 1) * W2_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks & 1, n = c ^ 1;
+            const unsigned char* rX = ks < 3 ? bX + ((((ks + 1) * 2 + h) ^ sz) << 4) : nX + ((h ^ nsz) << 4);
+            const unsigned char* rW = ks < 3 ? bW + ((((ks + 1) * 2 + h) ^ swzW) << 4) : nW + ((h ^ swzW) << 4);
+            if (ks == 3) {
+                // hand-over: every wave holds its last fragments of this chunk, the next chunk has landed
+                AZ_DMA_LANDED();
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#define MF4_(i_, j_) acc[i_][j_] = Prec<PR>::mfma(fw[c][i_], fx[c][j_], acc[i_][j_])
+#define FENCE4_ __builtin_amdgcn_sched_barrier(0)
+#define DMA4_(it_) do { if (ks == 3 && t + 2 < total) STAGE_W4(t + 2, it_); } while (0)
+            MF4_(0, 0); fx[n][0] = *(const vec*)(rX); FENCE4_;
+            MF4_(0, 1); fx[n][1] = *(const vec*)(rX + 4096); DMA4_(0); FENCE4_;
+            MF4_(1, 0); fw[n][0] = *(const vec*)(rW); FENCE4_;
+            MF4_(1, 1); fw[n][1] = *(const vec*)(rW + 4096); DMA4_(1); FENCE4_;
+            MF4_(2, 0); fw[n][2] = *(const vec*)(rW + 2 * 4096); FENCE4_;
+            MF4_(2, 1); fw[n][3] = *(const vec*)(rW + 3 * 4096); DMA4_(2); FENCE4_;
+            MF4_(3, 0); FENCE4_;
+            MF4_(3, 1); DMA4_(3); FENCE4_;
+#undef MF4_
+#undef FENCE4_
+#undef DMA4_
+        }
+        if (tap == 8 && t + 1 < total) {
+            // slice boundary: the slab is single-buffered.  The activation fragments just prefetched came from
+            // the old slab (harmless, dropped); reload the slab -- the co-resident workgroup has the MFMA
+            // pipes meanwhile -- and read them again.  The weight fragments are already those of chunk t + 1.
+            __syncthreads();                                 // every wave is done with the slab
+            STAGE_A4(kc + 1);
+            AZ_DMA_LANDED();
+            __syncthreads();
+            const unsigned char* rX = nX + ((h ^ nsz) << 4);
+            fx[0][0] = *(const vec*)(rX); fx[0][1] = *(const vec*)(rX + 4096);
+        }
+    }
+#undef STAGE_W4
+#undef STAGE_A4
+#undef CHUNK_SRC4
+    __syncthreads();                                         // all waves done with the buffers: LDS becomes the output image
+
+    // epilogue: 256 rows x 128 channels, 256-byte rows, piece c of row r at c ^ (r & 15)
+    unsigned char* const sO = smem;
+    if (resid) {
+        // DMA q covers image rows 4q .. 4q+3 (lane: row 4q + (lane >> 4), physical piece lane & 15 holds logical
+        // piece (lane & 15) ^ (row & 15) = ((lane & 15) ^ (lane >> 4)) ^ (4q & 15)); wave w issues q = w, w+4, ...
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(resid + (size_t)(Gd + m0) * C_pad + nb * 128), 0, T4_M * C_pad * 2, 0x00020000);
+        const unsigned lane_piece = (unsigned)((lane & 15) ^ (lane >> 4));
+        const unsigned row_off = (unsigned)((lane >> 4) * C_pad * 2);
+#pragma unroll 4
+        for (int q = wvu; q < T4_M / 4; q += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(sO + q * 1024), 16,
+                                                     row_off + ((lane_piece ^ (unsigned)((4 * q) & 15)) << 4), q * 4 * C_pad * 2, 0, 0);
+        AZ_DMA_LANDED();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rr = 64 * wv + 32 * j + l31;
+        const int m = m0 + rr;
+        const int pp = m % P;
+        const bool real = m < M && (pp / W) < N && (pp % W) < N;
+        const unsigned keep = real ? 0xFFFFFFFFu : 0u;
+        const float cap = real ? Prec<PR>::cap() : 0.f;
+        unsigned char* const rowp = sO + rr * 256 + 8 * h;
+        const int sw = rr & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4*)(bias + nb * 128 + 32 * i + 8 * q + 4 * h);
+                float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
+                float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
+                uint2* const slot = (uint2*)(rowp + (((4 * i + q) ^ sw) << 4));   // channels 32 i + 8 q + 4 h .. +3
+                if (resid) {
+                    const uint2 r2 = *slot;
+                    v0 += Prec<PR>::from16((unsigned short)(r2.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(r2.x >> 16));
+                    v2 += Prec<PR>::from16((unsigned short)(r2.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(r2.y >> 16));
+                }
+                uint2 o;
+                if (relu) {                                  // ReLU + saturation + padding mask: one v_med3 per value
+                    o.x = Prec<PR>::pack2(relu_cap(v0, cap), relu_cap(v1, cap));
+                    o.y = Prec<PR>::pack2(relu_cap(v2, cap), relu_cap(v3, cap));
+                } else {
+                    o.x = ((unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16)) & keep;
+                    o.y = ((unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16)) & keep;
+                }
+                *slot = o;
+            }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = tid; i < T4_M * 16; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sO + r * 256 + ((c ^ (r & 15)) << 4));
     }
 }
 
@@ -1155,6 +1359,7 @@ extern "C" int az_tower_configure(void) {
     hipError_t e = hipSuccess;
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
+    SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
     SETA(az_conv3x3_w256_kernel<0>, 160 * 1024); SETA(az_conv3x3_w256_kernel<1>, 160 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
     SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
@@ -1182,6 +1387,14 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short*
         const int wgs = tiles < 256 / col_blocks ? tiles : (256 / col_blocks > 0 ? 256 / col_blocks : 1);   // persistent: one workgroup per CU
         BY_PREC(az_conv3x3_w256_kernel, dim3(wgs, col_blocks), dim3(256), sm, s,
                 in, out, resid, wpk256, bias, C_pad, M, tiles, N, Gd, relu);
+        return;
+    }
+    if (!getenv("AZ_CONV_T128")) {                                        // 256 rows x 128 channels, two workgroups per CU
+        const int tiles = (M + T4_M - 1) / T4_M;
+        size_t sm = 2 * (size_t)W2_BYTES + (size_t)t4_slab_rows(Gd) * 128;
+        if (sm < (size_t)T4_M * 256) sm = (size_t)T4_M * 256;               // the epilogue image
+        BY_PREC(az_conv3x3_t256_kernel, dim3(tiles, C_pad / 128), dim3(256), sm, s,
+                in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu);
         return;
     }
     const int tiles = (M + T2_M - 1) / T2_M;

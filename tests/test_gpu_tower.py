@@ -164,6 +164,30 @@ def test_wide_tower_many_tiles_per_workgroup_matches_128_row_kernel(monkeypatch)
     assert np.abs(pol[pick] - rp).max() < TOL and np.abs(val[pick] - rv).max() < TOL
 
 
+def test_large_board_256_row_kernel_matches_128_row_kernel(monkeypatch):
+    """19x19 boards (400 raster rows: tiles straddle boards) on the 256-row x 128-channel per-layer kernel
+    against the 128-row kernel on the same weights, and a sample against torch fp32."""
+    import torch
+    torch.set_num_threads(8)
+    N, B, Cs = 19, 70, synth.NETCONFIG2                 # 70 boards x 400 rows = 110 tiles of 256 rows (ragged end)
+    blob = synth.make_blob(N, 3, Cs, 61)
+    boards = synth.random_boards(B, N, seed=61)
+    eng = capi.Engine(N, 5, B, Cs=Cs)
+    assert not eng.tower_is_fused()
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(boards)
+    eng.close()
+    monkeypatch.setenv("AZ_CONV_T128", "1")
+    eng2 = capi.Engine(N, 5, B, Cs=Cs)
+    eng2.load_weights(blob)
+    pol2, val2 = eng2.tower_forward(boards)
+    assert np.abs(pol - pol2).max() < 1e-4 and np.abs(val - val2).max() < 1e-3
+    pick = np.r_[0:3, 33:36, B - 3:B]
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, boards[pick])
+    assert np.abs(pol[pick] - rp).max() < TOL and np.abs(val[pick] - rv).max() < TOL
+
+
 def test_tower_requires_weights_and_uniform_widths():
     eng = capi.Engine(9, 5, 4, Cs=synth.NETCONFIG2)
     with pytest.raises(capi.AzError):
