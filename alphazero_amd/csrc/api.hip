@@ -47,7 +47,6 @@ struct az_ctx {
     bool fused = false;                                   // whole tower in one launch
     int prec = 0;                                         // 0 bf16, 1 fp16 operands
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
-    unsigned short* conv_w256 = nullptr;                  // widths that are multiples of 256: [layer][nb][slice][tap][n=256][k=64]
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
     float* head_p = nullptr;
     float* head_pt = nullptr;                             // fused path: 1x1 weights as {policy, value} pairs, fc1 transposed [A][64]
@@ -207,7 +206,6 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
             AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27));
             AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
-            if (c->C_pad % 256 == 0) AZCHK(dalloc(c, &c->conv_w256, c->conv_layer_elems * 2 * c->num_res));
             AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
         }
         AZCHK(dalloc(c, &c->tower_in, (size_t)c->Bmax * 3 * A));
@@ -334,31 +332,6 @@ extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
         }
     }
     if (!c->fused) HIPCHK(hipMemcpy(c->conv_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
-    if (c->conv_w256) {
-        // the 256 x 256 kernel's image: 32 KB chunks [nb][slice of 64 input channels][tap][n=256][k=64], stored
-        // as the kernel reads them from LDS (16-byte piece q of row n at piece q ^ ((n >> 1) & 7))
-        const int n_kc = Cp / 64;
-        std::vector<unsigned short> p2(c->conv_layer_elems * 2 * nres, 0);
-        for (int L = 0; L < 2 * nres; ++L) {
-            const Conv& cv = (L & 1) ? c2[L / 2] : c1[L / 2];
-            const Bn& bb = (L & 1) ? b2[L / 2] : b1[L / 2];
-            unsigned short* dst = p2.data() + (size_t)L * c->conv_layer_elems;
-            for (int co = 0; co < C; ++co) {
-                const double s = scale(bb, co);
-                const int nb2 = co / 256, n = co % 256;
-                for (int ci = 0; ci < C; ++ci) {
-                    const int kc = ci / 64, k = ci % 64;
-                    const int piece = (k >> 3) ^ ((n >> 1) & 7);
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const size_t chunk = ((size_t)nb2 * n_kc + kc) * 9 + tap;
-                        dst[chunk * (256 * 64) + (size_t)n * 64 + piece * 8 + (k & 7)] =
-                            to16((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
-                    }
-                }
-            }
-        }
-        HIPCHK(hipMemcpy(c->conv_w256, p2.data(), p2.size() * 2, hipMemcpyHostToDevice));
-    }
     if (c->fused) {                               // one 32 KB chunk per tap: [layer][tap][n][k]
         std::vector<unsigned short> pf((size_t)2 * nres * 9 * 128 * 128, 0);
         for (int L = 0; L < 2 * nres; ++L) {
@@ -431,13 +404,11 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
-        const unsigned short* x1 = c->conv_w256 ? c->conv_w256 + (size_t)(2 * i) * c->conv_layer_elems : nullptr;
-        const unsigned short* x2 = c->conv_w256 ? c->conv_w256 + (size_t)(2 * i + 1) * c->conv_layer_elems : nullptr;
         bool on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->actX, c->actH, nullptr, w1, x1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->actX, c->actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
         on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->actH, c->actX, c->actX, w2, x2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->actH, c->actX, c->actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
     }
     az_launch_heads(c->stream, c->prec, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);

@@ -5,7 +5,7 @@
 //                     launch, activations resident in LDS (C <= 128, (N+1)^2 <= 256)
 //   az_stem_kernel    ConvBlock (network.hpp:15-17): 3x3 conv on the u8 planes,
 //                     BN folded, ReLU; fp32 VALU                       } per-layer
-//   az_conv3x3_t256_kernel, az_conv3x3_w256_kernel, az_conv3x3_t128_kernel } path for
+//   az_conv3x3_t256_kernel, az_conv3x3_t128_kernel                      } path for
 //                     ResBlock convolutions (network.hpp:32-38) as      } wider or
 //                     implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}:  } larger
 //                     D[ch][pos] = sum_k W[ch][k] X[k][pos]             } shapes
@@ -325,7 +325,7 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
 }
 
 // ------------------------------------- conv 3x3, 256 rows x 128 channels, two workgroups per CU
-// For boards larger than one LDS tile (N > 15) and widths that are not multiples of 256.  The 128-row
+// The default per-layer kernel (boards larger than one LDS tile, N > 15, or C > 128).  The 128-row
 // kernel above asks L2 for a weight byte per 128 rows (32 B/clk per CU with two workgroups resident:
 // at the limit of what a CU gets from L2); this one keeps the two-workgroups-per-CU overlap (72 KB of
 // LDS, 256 registers) but covers 256 rows per weight byte: wave w owns positions [64w, 64w+64) and all
@@ -526,274 +526,6 @@ az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* ou
         const int r = i >> 4, c = i & 15;
         *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sO + r * 256 + ((c ^ (r & 15)) << 4));
     }
-}
-
-// ------------------------------------- conv 3x3, 256 rows x 256 channels per workgroup
-// For towers whose width is a multiple of 256 (the 20-block x 256-channel stress shape): one
-// workgroup computes ALL 256 output channels of a column block for 256 rows, so every activation
-// byte is staged once per layer instead of once per 128 output channels, and a weight byte feeds
-// twice the rows of the 128-row kernel above (that kernel asks L2 for ~8 TB/s of weights).
-// grid (M_pad/256, C_pad/256), 256 threads = 4 waves as 2 x 2: wave (wm, wn) owns positions
-// [128 wm, +128) x channels [128 wn, +128) = 4 x 4 accumulator tiles of 32(ch) x 32(pos), 256
-// accumulator registers; one k-step = 16 MFMAs on 4 weight + 4 activation fragments.
-// The reduction runs over 64-channel input slices x 9 taps.  Per (slice, tap) one 32 KB weight
-// chunk [n=256][k=64] streams through a double buffer; per slice one activation slab
-// [256 + 2 Gd rows][64 ch] (128-byte rows) through a second double buffer, both by buffer-addressed
-// LDS DMA.  128-byte rows: 16-byte piece c of row r lives at piece c ^ ((r >> 1) & 7) (two rows per
-// bank sweep); the weight image is stored pre-swizzled, the slab is swizzled through the source
-// address of each DMA lane.  Reads beyond the activation buffer return zero (buffer bounds).
-#define T3_M 256
-#define W3_BYTES (256 * 128)     // one (slice, tap) chunk of weights: 256 rows (n) x 64 k, 16-bit
-static inline __host__ __device__ int t3_slab_rows(int Gd) { return (T3_M + 2 * Gd + 7) / 8 * 8; }
-
-#ifdef AZ_TOWER_TIMING
-__device__ unsigned long long az_w256_ts[16];
-extern "C" int az_w256_timing_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(az_w256_ts), sizeof(unsigned long long) * 16);
-}
-#define T3STAMP(slot_) do { if (blockIdx.x == 200 && blockIdx.y == 0 && threadIdx.x == 0) az_w256_ts[slot_] = __builtin_readcyclecounter(); } while (0)
-#else
-#define T3STAMP(slot_) do {} while (0)
-#endif
-
-// Epilogue of the 256 x 256 kernel: + bias (+ residual), ReLU, zero padding rows.  HBM wants whole
-// rows, the accumulator layout gives a lane 8 bytes in each of 32 rows, so the tile goes through a
-// 256-row image in LDS (512-byte rows, 16-byte piece c of row r at piece c ^ (r & 31)): residual rows
-// in by LDS DMA (no registers: with 256 accumulators live the compiler otherwise serialises register
-// loads one at a time), arithmetic in place, rows out.
-template <int PR, bool RES, bool RELU>
-__device__ __forceinline__ void w256_epilogue(f32x16 (&acc)[4][4], const unsigned short* resid /* may alias out */,
-                                              unsigned short* out, const float* s_bias, unsigned char* sO,
-                                              int C_pad, int M, int m0, int nb, int N, int Gd, int tid, int wvu, int wm, int wn,
-                                              int l31, int h) {
-    const int W = N + 1, P = W * W;
-    // the epilogue's index arithmetic is invariant across the kernel's tile loop: left alone, the compiler
-    // hoists all of it out of that loop and keeps ~60 registers live through the MFMA loop (spills);
-    // these empty asm statements make the lane ids opaque so that it is recomputed here
-    asm volatile("" : "+v"(tid), "+v"(l31), "+v"(h));
-    asm volatile("" : "+v"(wm), "+v"(wn));
-    if (RES) {
-        // DMA q covers image rows 2q, 2q+1 (lane: row 2q + (lane >> 5), physical piece lane & 31 holds logical
-        // piece (lane & 31) ^ (row & 31) = ((lane & 31) ^ (lane >> 5)) ^ (2q & 31)); wave w issues q = w, w+4, ...
-        const int lane = tid & 63;
-        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(resid + (size_t)(Gd + m0) * C_pad + nb * 256), 0, T3_M * C_pad * 2, 0x00020000);
-        const unsigned lane_piece = (unsigned)((lane & 31) ^ (lane >> 5));
-        const unsigned row_off = (unsigned)((lane >> 5) * C_pad * 2);
-#pragma unroll 4
-        for (int q = wvu; q < T3_M / 2; q += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(sO + q * 1024), 16,
-                                                     row_off + ((lane_piece ^ (unsigned)((2 * q) & 31)) << 4), q * 2 * C_pad * 2, 0, 0);
-        AZ_DMA_LANDED();
-        __syncthreads();
-    }
-    T3STAMP(3);
-    const float* const brow = s_bias + 128 * wn + 4 * h;     // this column block's 256 biases, staged in LDS by the kernel
-    float cap[4];
-    unsigned keep[4];
-    unsigned char* rowp[4];
-    int sw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rr = 128 * wm + 32 * j + l31;
-        const int m = m0 + rr;
-        const int pp = m % P;
-        const bool real = m < M && (pp / W) < N && (pp % W) < N;
-        keep[j] = real ? 0xFFFFFFFFu : 0u;
-        cap[j] = real ? Prec<PR>::cap() : 0.f;
-        rowp[j] = sO + rr * 512 + 8 * (h & 1);
-        sw[j] = rr & 31;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bq = *(const float4*)(brow + 32 * i + 8 * q);
-            const int piece = 16 * wn + 4 * i + q;           // channels 128 wn + 32 i + 8 q + 4 h .. +3: logical piece, half h
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v0 = acc[i][j][4 * q + 0] + bq.x, v1 = acc[i][j][4 * q + 1] + bq.y;
-                float v2 = acc[i][j][4 * q + 2] + bq.z, v3 = acc[i][j][4 * q + 3] + bq.w;
-                uint2* const slot = (uint2*)(rowp[j] + ((piece ^ sw[j]) << 4));
-                if (RES) {
-                    const uint2 r2 = *slot;
-                    v0 += Prec<PR>::from16((unsigned short)(r2.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(r2.x >> 16));
-                    v2 += Prec<PR>::from16((unsigned short)(r2.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(r2.y >> 16));
-                }
-                uint2 o;
-                if (RELU) {                                  // ReLU + saturation + padding mask: one v_med3 per value
-                    o.x = Prec<PR>::pack2(relu_cap(v0, cap[j]), relu_cap(v1, cap[j]));
-                    o.y = Prec<PR>::pack2(relu_cap(v2, cap[j]), relu_cap(v3, cap[j]));
-                } else {
-                    o.x = ((unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16)) & keep[j];
-                    o.y = ((unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16)) & keep[j];
-                }
-                *slot = o;
-            }
-        }
-    __syncthreads();
-    T3STAMP(4);
-#pragma unroll 4
-    for (int i = tid; i < T3_M * 32; i += 256) {
-        const int r = i >> 5, c = i & 31;
-        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 256 + c * 8) = *(const uint4*)(sO + r * 512 + ((c ^ (r & 31)) << 4));
-    }
-    __syncthreads();                                         // the image is the next tile's buffers
-}
-
-template <int PR>
-__global__ void __launch_bounds__(256)
-az_conv3x3_w256_kernel(const unsigned short* __restrict__ in, unsigned short* out,
-                       const unsigned short* resid /* may alias out */, const unsigned short* __restrict__ wpk,
-                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef typename Prec<PR>::vec vec;
-    const int W = N + 1;
-    const int rows_total = n_tiles * T3_M + 2 * Gd;          // rows of the activation buffers
-    const int slab_rows = t3_slab_rows(Gd);
-    const int slab_bytes = slab_rows * 128;
-    unsigned char* sW = smem;                                // 2 x W3_BYTES
-    unsigned char* sA = smem + 2 * W3_BYTES;                 // 2 x slab_bytes
-    float* sBias = (float*)(sA + 2 * slab_bytes);            // [256] this column block's biases
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wv & 1, wn = wv >> 1;
-    const int nb = blockIdx.y;
-    const int n_kc = C_pad / 64;
-    const int total = n_kc * 9;                              // (slice, tap) chunks of this column block
-    T3STAMP(0);
-
-    // weight stream: chunk t = kc*9 + tap is a straight 32 KB copy; wave w moves bytes [8192 w, +8192)
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(wpk + (size_t)nb * total * (256 * 64)), 0, total * W3_BYTES, 0x00020000);
-    unsigned char* const w_dst = sW + wvu * 8192;
-    const unsigned w_voff = (unsigned)lane * 16u;
-#define STAGE_W3(t_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
-        wrsrc, (lds_void*)(w_dst + ((t_) & 1) * W3_BYTES + (it_) * 1024), 16, w_voff, \
-        (t_) * W3_BYTES + wvu * 8192 + (it_) * 1024, 0, 0)
-    // activation slab: DMA q covers slab rows 8q .. 8q+7 (lane: row 8q + (lane >> 3), physical piece
-    // lane & 7); wave w issues q = w, w+4, ... so q & 1 == w & 1 and the row's swizzle term
-    // ((row >> 1) & 7) = 4 (w & 1) + (lane >> 4) is one per-lane constant
-    // (the resource is rebased to the tile's first row, so offsets stay small whatever the batch)
-#define SLAB_RSRC(m0_) __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)(m0_) * C_pad), 0, \
-        (int)((size_t)(rows_total - (m0_)) * C_pad * 2 < 0x7FFFFFFFull ? (size_t)(rows_total - (m0_)) * C_pad * 2 : 0x7FFFFFFFull), 0x00020000)
-    const unsigned a_voff = (unsigned)((lane >> 3) * C_pad * 2 + (((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7)) << 4));
-    const int n_q = slab_rows / 8;
-#define STAGE_A3(rs_, kc_) do { \
-        for (int q_ = wvu; q_ < n_q; q_ += 4) \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void*)(sA + ((kc_) & 1) * slab_bytes + q_ * 1024), 16, \
-                                                     a_voff, q_ * 8 * C_pad * 2 + (kc_) * 128, 0, 0); \
-    } while (0)
-    // a tile's first two weight chunks and its first slab: issued before the first tile and, for every
-    // later tile, under the epilogue of the tile before it
-#define TILE_PROLOGUE(rs_) do { \
-        _Pragma("unroll") for (int it = 0; it < 8; ++it) STAGE_W3(0, it); \
-        _Pragma("unroll") for (int it = 0; it < 8; ++it) STAGE_W3(1, it);   /* total >= 36: chunk 1 always exists */ \
-        STAGE_A3(rs_, 0); \
-    } while (0)
-
-    sBias[tid] = bias[blockIdx.y * 256 + tid];               // visible after the first tile's barrier
-    // persistent: workgroup x takes tiles x, x + gridDim.x, ...
-    int tile = blockIdx.x;
-    __amdgpu_buffer_rsrc_t arsrc = SLAB_RSRC(tile * T3_M);
-    TILE_PROLOGUE(arsrc);
-    for (; tile < n_tiles; tile += gridDim.x) {
-    const int m0 = tile * T3_M;
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    AZ_DMA_LANDED();
-    __syncthreads();
-    T3STAMP(1);
-
-    const int s_base = Gd + 128 * wm + l31;                  // slab row of this lane's first position
-    const int swzW = (l31 >> 1) & 7;
-    const unsigned char* const wrow = sW + (128 * wn + l31) * 128;
-    vec fx[2][4], fw[2][4];
-    {
-        const int s0 = s_base - W - 1;                       // tap 0
-        const int sz = (s0 >> 1) & 7;
-        const unsigned char* bX = sA + s0 * 128 + ((h ^ sz) << 4);
-        const unsigned char* bW = wrow + ((h ^ swzW) << 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fx[0][j] = *(const vec*)(bX + j * 4096);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fw[0][i] = *(const vec*)(bW + i * 4096);
-    }
-    for (int t = 0; t < total; ++t) {
-        const int kc = t / 9, tap = t - 9 * kc;
-        const int tn_ = t + 1 < total ? t + 1 : t;           // the chunk after this one (the last re-reads itself)
-        const int nkc = tn_ / 9, ntap = tn_ - 9 * nkc;
-        const int s0 = s_base + (tap / 3 - 1) * W + (tap % 3 - 1);
-        const int ns0 = s_base + (ntap / 3 - 1) * W + (ntap % 3 - 1);
-        const int sz = (s0 >> 1) & 7, nsz = (ns0 >> 1) & 7;
-        const unsigned char* bX = sA + (kc & 1) * slab_bytes + s0 * 128;
-        const unsigned char* nX = sA + (nkc & 1) * slab_bytes + ns0 * 128;
-        const unsigned char* bW = wrow + (t & 1) * W3_BYTES;
-        const unsigned char* nW = wrow + ((t + 1) & 1) * W3_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = ks & 1, n = c ^ 1;
-            const unsigned char* rX = ks < 3 ? bX + ((((ks + 1) * 2 + h) ^ sz) << 4) : nX + ((h ^ nsz) << 4);
-            const unsigned char* rW = ks < 3 ? bW + ((((ks + 1) * 2 + h) ^ swzW) << 4) : nW + ((h ^ swzW) << 4);
-            if (ks == 3) {
-                // hand-over: every wave holds its last fragments of this chunk, the next chunk (and, at a
-                // slice boundary, the next slab) has landed
-                AZ_DMA_LANDED();
-                __syncthreads();
-                // the other slab buffer was last read by the previous slice: free after this barrier
-                if (tap == 0 && kc + 1 < n_kc) STAGE_A3(arsrc, kc + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#define MF3_(i_, j_) acc[i_][j_] = Prec<PR>::mfma(fw[c][i_], fx[c][j_], acc[i_][j_])
-#define LDX3_(j_) fx[n][j_] = *(const vec*)(rX + (j_) * 4096)
-#define LDW3_(i_) fw[n][i_] = *(const vec*)(rW + (i_) * 4096)
-#define FENCE3_ __builtin_amdgcn_sched_barrier(0)
-            // this chunk's weight buffer is free after the hand-over: the chunk after next goes into it, one
-            // 1 KB piece per wave after every second MFMA (a burst of eight stalls the wave on the memory
-            // pipeline's issue queue for ~60 cycles a piece)
-#define DMA3_(it_) do { if (ks == 3 && t + 2 < total) STAGE_W3(t + 2, it_); } while (0)
-            MF3_(0, 0); LDX3_(0); FENCE3_; MF3_(1, 0); LDW3_(0); DMA3_(0); FENCE3_;
-            MF3_(2, 0); LDX3_(1); FENCE3_; MF3_(3, 0); LDW3_(1); DMA3_(1); FENCE3_;
-            MF3_(0, 1); LDX3_(2); FENCE3_; MF3_(1, 1); LDW3_(2); DMA3_(2); FENCE3_;
-            MF3_(2, 1); LDX3_(3); FENCE3_; MF3_(3, 1); LDW3_(3); DMA3_(3); FENCE3_;
-            MF3_(0, 2); MF3_(1, 2); DMA3_(4); FENCE3_; MF3_(2, 2); MF3_(3, 2); DMA3_(5); FENCE3_;
-            MF3_(0, 3); MF3_(1, 3); DMA3_(6); FENCE3_; MF3_(2, 3); MF3_(3, 3); DMA3_(7); FENCE3_;
-#undef DMA3_
-#undef MF3_
-#undef LDX3_
-#undef LDW3_
-#undef FENCE3_
-        }
-    }
-    __syncthreads();                                         // all waves done with the buffers
-    T3STAMP(2);
-    unsigned char* const stg = smem;                         // the output image takes the weight and slab buffers
-    if (resid) {
-        if (relu) w256_epilogue<PR, true, true>(acc, resid, out, sBias, stg, C_pad, M, m0, nb, N, Gd, tid, wvu, wm, wn, l31, h);
-        else w256_epilogue<PR, true, false>(acc, resid, out, sBias, stg, C_pad, M, m0, nb, N, Gd, tid, wvu, wm, wn, l31, h);
-    } else {
-        if (relu) w256_epilogue<PR, false, true>(acc, resid, out, sBias, stg, C_pad, M, m0, nb, N, Gd, tid, wvu, wm, wn, l31, h);
-        else w256_epilogue<PR, false, false>(acc, resid, out, sBias, stg, C_pad, M, m0, nb, N, Gd, tid, wvu, wm, wn, l31, h);
-    }
-    T3STAMP(6);
-    if (tile + (int)gridDim.x < n_tiles) {
-        arsrc = SLAB_RSRC((tile + (int)gridDim.x) * T3_M);
-        TILE_PROLOGUE(arsrc);
-    }
-    T3STAMP(5);
-    }
-#undef STAGE_W3
-#undef STAGE_A3
-#undef TILE_PROLOGUE
-#undef SLAB_RSRC
 }
 
 // ------------------------------------------------------------ fused tower
@@ -1360,7 +1092,6 @@ extern "C" int az_tower_configure(void) {
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
-    SETA(az_conv3x3_w256_kernel<0>, 160 * 1024); SETA(az_conv3x3_w256_kernel<1>, 160 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
     SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
     SETA((az_tower_fused_kernel<0, 1>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1>), 160 * 1024);
@@ -1378,17 +1109,8 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
 }
 
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
-                                  const unsigned short* resid, const unsigned short* wpk, const unsigned short* wpk256,
-                                  const float* bias, int C_pad, int M, int N, int Gd, int relu) {
-    if (wpk256 && C_pad % 256 == 0 && !getenv("AZ_CONV_T128")) {          // 256 rows x 256 channels per workgroup
-        const int tiles = (M + T3_M - 1) / T3_M;
-        const size_t sm = 2 * (size_t)W3_BYTES + 2 * (size_t)t3_slab_rows(Gd) * 128 + 1024;
-        const int col_blocks = C_pad / 256;
-        const int wgs = tiles < 256 / col_blocks ? tiles : (256 / col_blocks > 0 ? 256 / col_blocks : 1);   // persistent: one workgroup per CU
-        BY_PREC(az_conv3x3_w256_kernel, dim3(wgs, col_blocks), dim3(256), sm, s,
-                in, out, resid, wpk256, bias, C_pad, M, tiles, N, Gd, relu);
-        return;
-    }
+                                  const unsigned short* resid, const unsigned short* wpk, const float* bias,
+                                  int C_pad, int M, int N, int Gd, int relu) {
     if (!getenv("AZ_CONV_T128")) {                                        // 256 rows x 128 channels, two workgroups per CU
         const int tiles = (M + T4_M - 1) / T4_M;
         size_t sm = 2 * (size_t)W2_BYTES + (size_t)t4_slab_rows(Gd) * 128;

@@ -251,7 +251,7 @@ def main():
         sims = sims_all                                    # counted on the device, one per backup
         B = batch * NC                      # boards per evaluation launch (x NC: divided again below)
         conv_flops = 2.0 * 9 * A * C * C * B               # one 3x3 conv over B boards, real cells only
-        kernel = "az_conv3x3_w256_kernel" if C % 256 == 0 else "az_conv3x3_t256_kernel"
+        kernel = "az_conv3x3_t256_kernel"
         if fused:                           # stem + all 2*num_res convs in one launch
             conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * B) / NC   # per launch of one context
             kernel = "az_tower_fused_kernel"
