@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("AZ_HIP_LIB") or os.path.join(_HERE, "libazhip.so")   
 
 AZ_EVAL_TOWER, AZ_EVAL_HASH, AZ_EVAL_EXTERNAL = 0, 1, 2
 AZ_NOISE_EXPLICIT, AZ_NOISE_DEVICE = 0, 1
-AZ_PREC_BF16, AZ_PREC_FP16 = 0, 1
+AZ_PREC_FP16, AZ_PREC_BF16 = 0, 1          # fp16 operands are the default (1e-3 parity mode)
 AZ_MAX_LAYERS = 64
 AZ_OK, AZ_E_ARG, AZ_E_HIP, AZ_E_CAPACITY, AZ_E_STATE, AZ_E_NOWEIGHTS = 0, -1, -2, -3, -4, -5
 
@@ -86,7 +86,7 @@ class Engine:
     + PVNetwork (mcts.hpp, evaluator.hpp, network.hpp) behind one handle."""
 
     def __init__(self, N, K, G, Cs=None, vl=3.0, c_puct=3.0, max_budget=800, node_cap=0,
-                 eval_mode=AZ_EVAL_TOWER, noise_mode=AZ_NOISE_EXPLICIT, precision=AZ_PREC_BF16,
+                 eval_mode=AZ_EVAL_TOWER, noise_mode=AZ_NOISE_EXPLICIT, precision=AZ_PREC_FP16,
                  seed=0, device=0, game_slot_base=0, leaves_per_round=1):
         L = load()
         cfg = AzConfig()

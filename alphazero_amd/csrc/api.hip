@@ -190,8 +190,11 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         c->C = cfg->Cs[0];
         c->C_pad = (c->C + 127) / 128 * 128;
         c->num_res = cfg->n_Cs - 1;
-        c->prec = cfg->precision == AZ_PREC_FP16 ? 1 : 0;
-        c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED");
+        c->prec = cfg->precision == AZ_PREC_BF16 ? 0 : 1;           // kernel template index: 0 bf16, 1 fp16
+        // whole tower in one launch when a board fits one 256-row LDS tile and the bias table of all
+        // layers still fits beside it (160 KB per CU); otherwise one launch per convolution
+        c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED") &&
+                   az_tower_fused_lds_bytes(N, 2 * c->num_res, 256) <= 160 * 1024;
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
         AZCHK(dalloc(c, &c->stem_b, c->C_pad));
         AZCHK(dalloc(c, &c->conv_b, (size_t)2 * c->num_res * c->C_pad));

@@ -25,7 +25,7 @@ enum { AZ_ST_IDLE = 0, AZ_ST_RUN = 1 };
 enum { AZ_MODE_SEARCH = 0, AZ_MODE_SELFPLAY = 1 };
 
 // All per-game state, structure-of-arrays over the G games of one GPU.
-enum { AZ_GC_EVALS = 0, AZ_GC_DESCENTS = 1, AZ_GC_LEVELS = 2, AZ_GC_SCANNED = 3, AZ_GC_EXPANDED = 4, AZ_GC_STRIDE = 8 };
+enum { AZ_GC_EVALS = 0, AZ_GC_DESCENTS = 1, AZ_GC_LEVELS = 2, AZ_GC_SCANNED = 3, AZ_GC_EXPANDED = 4, AZ_GC_RESTARTS = 5, AZ_GC_STRIDE = 8 };
 
 struct AzTreeDev {
     int G, N, A, K;
@@ -66,7 +66,7 @@ struct AzTreeDev {
     int*      path_len;         // [G*L]
     int*      path;             // [G*L][path_cap] edge indices root->leaf
     float*    pend_result;      // [G*L][2] reward of a terminal leaf
-    int*      err;              // [G] sticky error flag (arena overflow)
+    int*      err;              // [G] sticky error flag (2: no selectable child, mcts.hpp:374-375)
 
     // evaluator I/O
     uint8_t*  leaf_planes;      // [G*L][3][A]
@@ -96,7 +96,8 @@ struct AzTreeDev {
     unsigned long long* g_ctr;          // [G][AZ_GC_STRIDE] per-game tallies (one 64-byte line per game, no shared hot word):
                                         //   AZ_GC_EVALS boards submitted to the evaluator, AZ_GC_DESCENTS descents that stood,
                                         //   AZ_GC_LEVELS tree levels they walked, AZ_GC_SCANNED child edges they read,
-                                        //   AZ_GC_EXPANDED child edges written by expansions
+                                        //   AZ_GC_EXPANDED child edges written by expansions, AZ_GC_RESTARTS searches
+                                        //   restarted from a fresh root because the arena was full
     int*      g_hw_nodes;       // [G] arena high-water marks, noted when a tree shrinks
     int*      g_hw_edges;       // [G]
 };

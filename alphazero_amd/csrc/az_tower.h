@@ -1,10 +1,13 @@
 // Host-side launchers of the tower kernels (tower.hip).  prec: 0 bf16, 1 fp16 operands.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 extern "C" {
 int  az_tower_configure(void);
+size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows);   // dynamic LDS of az_tower_fused_kernel
+
 void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, const float* w,
                     const float* bias, int B, int N, int C_pad, int Gd);
 void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,

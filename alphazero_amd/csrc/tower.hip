@@ -740,8 +740,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     unsigned char* sB = smem + (size_t)a_rows * A_STRIDE;
     unsigned char* sI = sB;                                  // stem im2col [TM][I_STRIDE]
     unsigned char* sW = sB + TM * I_STRIDE;                  // stem weights [128][I_STRIDE]
-    float* sBias = (float*)(sB + 2 * W_BUF_BYTES);           // [n_layers + 1][128]: stem bias, then every conv's
-    uint8_t* sP = (uint8_t*)(sBias + (n_layers + 1) * 128);  // planes of this tile's boards
+    float* sBias = (float*)(sB + 2 * W_BUF_BYTES);           // [n_layers + 2][128]: stem bias, every conv's, a row of zeros
+    uint8_t* sP = (uint8_t*)(sBias + (n_layers + 2) * 128);  // planes of this tile's boards
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -768,8 +768,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     // all biases into LDS once: the per-layer epilogue then never waits on HBM/L2
     const int nb4 = (n_layers + 1) * 32;                     // float4s: stem bias, then every conv's
 #pragma unroll 3
-    for (int i = tid; i < nb4; i += 256)
-        ((float4*)sBias)[i] = i < 32 ? ((const float4*)stem_b)[i] : ((const float4*)bias)[i - 32];
+    for (int i = tid; i < nb4 + 32; i += 256)
+        ((float4*)sBias)[i] = i < 32 ? ((const float4*)stem_b)[i] : (i < nb4 ? ((const float4*)bias)[i - 32] : make_float4(0.f, 0.f, 0.f, 0.f));
     for (int i = tid; i < 2 * Gd * (A_STRIDE / 16); i += 256) {
         const int r = i / (A_STRIDE / 16), c = i % (A_STRIDE / 16);
         *(uint4*)(sA + (size_t)(r < Gd ? r : r + TM) * A_STRIDE + c * 16) = make_uint4(0, 0, 0, 0);
@@ -868,7 +868,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int posrow0 = Gd + PW * wv + l31;
     const int n_blocks = n_layers >> 1;
     for (int b = 0; b < n_blocks; ++b) {
-        const int nb1 = min(3 + 2 * b, n_layers), nb2 = min(4 + 2 * b, n_layers);     // next block's biases
+        // next block's biases; after the last block X restarts from the zero row: the heads read relu(x) itself
+        const int nb1 = min(3 + 2 * b, n_layers), nb2 = b + 1 < n_blocks ? 4 + 2 * b : n_layers + 1;
         fused_conv_taps<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         // (the barrier before the last k-step: all waves have finished reading this layer's input)
         TSTAMP(2 + 4 * b);
@@ -893,7 +894,6 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         float* s_red = s_part + 256;                 // [8]
         int* s_map = (int*)(s_red + 8);              // [A] cell -> padded-raster row
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2* wpv = (const f32x2*)hp;         // {policy weight, value weight} of channel c: one packed FMA feeds both heads
         const float bp = hp[256], bvv = hp[257];
         const float* fc1t = hp + 258;
         const float* fc1b = fc1t + 64 * A;
@@ -902,25 +902,41 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         const int r = tid;
         const int pp = r % P, py = pp / W, px = pp % W;
         const bool cell = r < rows_here && py < N && px < N;
-        f32x2 spv = {0.f, 0.f};
-        if (cell) {
-            const unsigned char* row = sA + (size_t)(Gd + r) * A_STRIDE;
-#pragma unroll 4
-            for (int c = 0; c < 128; c += 8) {
-                const uint4 v = *(const uint4*)(row + c * 2);
-                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        // Both 1x1 convolutions straight from the fp32 residual tile X (= relu(x), the last epilogue added a
+        // zero bias): a lane holds 64 of the 128 channels of each of its J positions, the other half sits in
+        // lane ^ 32.  Nothing is rounded to 16 bits between the last ResBlock and the heads.
+        f32x2 spv[J];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float lo = Prec<PR>::from16((unsigned short)(u[t] & 0xFFFFu));
-                    const float hi = Prec<PR>::from16((unsigned short)(u[t] >> 16));
-                    spv += (f32x2){lo, lo} * wpv[c + 2 * t];
-                    spv += (f32x2){hi, hi} * wpv[c + 2 * t + 1];
+        for (int j = 0; j < J; ++j) spv[j] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w01 = *(const float4*)(hp + 2 * (32 * i + 8 * q + 4 * h));       // {wp, wv} of channels c, c+1
+                const float4 w23 = *(const float4*)(hp + 2 * (32 * i + 8 * q + 4 * h) + 4);   // c+2, c+3
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float x0 = X[i][j][4 * q + 0], x1 = X[i][j][4 * q + 1];
+                    const float x2 = X[i][j][4 * q + 2], x3 = X[i][j][4 * q + 3];
+                    spv[j] += (f32x2){x0, x0} * (f32x2){w01.x, w01.y};
+                    spv[j] += (f32x2){x1, x1} * (f32x2){w01.z, w01.w};
+                    spv[j] += (f32x2){x2, x2} * (f32x2){w23.x, w23.y};
+                    spv[j] += (f32x2){x3, x3} * (f32x2){w23.z, w23.w};
                 }
             }
-        }
         TSTAMP(43);
-        s_logit[r] = cell ? spv.x + bp : -3.4e38f;
-        s_u[r] = cell ? fmaxf(spv.y + bvv, 0.f) : 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float lp = spv[j].x + __shfl_xor(spv[j].x, 32, 64);
+            const float lv = spv[j].y + __shfl_xor(spv[j].y, 32, 64);
+            if (h == 0) {
+                const int row = PW * wv + 32 * j + l31;
+                const bool real = keepcap[j] != 0.f;
+                s_logit[row] = real ? lp + bp : -3.4e38f;
+                s_u[row] = real ? fmaxf(lv + bvv, 0.f) : 0.f;
+            }
+        }
+        if (TM < 256 && tid < 256 - TM) { s_logit[TM + tid] = -3.4e38f; s_u[TM + tid] = 0.f; }
         for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
         __syncthreads();
         // softmax over each board's cells, reductions in a fixed order (deterministic bits)
@@ -1088,6 +1104,13 @@ az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ 
 
 // ------------------------------------------------------------ host launchers
 
+// dynamic LDS of the fused kernel: activations + two weight buffers + bias table + planes
+extern "C" size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows) {
+    const int P = (N + 1) * (N + 1), Gd = N + 2;
+    return (size_t)(rows + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)(n_layers + 2) * 128 * 4 +
+           (size_t)(rows / P) * 3 * N * N + 16;
+}
+
 extern "C" int az_tower_configure(void) {
     hipError_t e = hipSuccess;
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
@@ -1143,8 +1166,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     }
     const int bpt = rows / P;
     const int tiles = (B + bpt - 1) / bpt;
-    const size_t sm = (size_t)(rows + 2 * Gd) * A_STRIDE + 2 * W_BUF_BYTES + (size_t)(n_layers + 1) * 128 * 4 +
-                      (size_t)bpt * 3 * N * N + 16;
+    const size_t sm = az_tower_fused_lds_bytes(N, n_layers, rows);
     if (rows == 128) {
         if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, 1>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
         else hipLaunchKernelGGL((az_tower_fused_kernel<0, 1>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);

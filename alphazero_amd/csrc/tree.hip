@@ -259,7 +259,18 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         const int nn = uni(d.n_nodes[g]), ne0 = uni(d.n_edges[g]);
         const int legal = A - (hl + plen);
         if (nn >= d.node_cap || ne0 + legal > d.edge_cap) {
-            if (threadIdx.x == 0) { d.err[g] = 1; d.status[g] = AZ_ST_IDLE; d.pending[slot] = AZ_PEND_NONE; }
+            // The arena is full (the reference's heap has no such limit).  Give the tree up and search this
+            // position again from a fresh root, which is what __make_root does whenever find() misses
+            // (mcts.hpp:392-414): the slot keeps playing, the event is tallied per game.  Evaluations of this
+            // round that are still pending belong to the dropped tree and are discarded with it.
+            for (int t = threadIdx.x; t < plen; t += AZ_WAVE) s_cells[s_act[t]] = 0;
+            __syncthreads();
+            az_drop_tree(d, g);
+            if (threadIdx.x == 0) {
+                d.sims_done[g] = 0;
+                for (int kk = 0; kk < d.L; ++kk) d.pending[g * d.L + kk] = AZ_PEND_NONE;
+                d.g_ctr[(size_t)g * AZ_GC_STRIDE + AZ_GC_RESTARTS] += 1ull;
+            }
             __syncthreads();
             return;
         }

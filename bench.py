@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--budget", type=int, default=800)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16"], default="fp16")
     ap.add_argument("--contexts", type=int, default=1,
                     help="split the GPU's games over this many engine contexts (own stream each) so that one "
                          "context's tree kernel overlaps another's tower")

@@ -42,9 +42,11 @@ extern "C" {
 /* noise_mode */
 #define AZ_NOISE_EXPLICIT 0  /* Dirichlet noise from az_set_noise */
 #define AZ_NOISE_DEVICE   1  /* drawn on the device, alpha = 0.05 (util.h:42) */
-/* precision of the tower's 3x3 convolutions */
-#define AZ_PREC_BF16     0   /* bf16 operands, fp32 accumulate (MFMA) */
-#define AZ_PREC_FP16     1   /* fp16 operands (saturating), fp32 accumulate: same MFMA rate, 8x finer rounding */
+/* operand format of the tower's 3x3 convolutions (fp32 accumulate, fp32 residual stream, fp32 heads) */
+#define AZ_PREC_FP16     0   /* fp16 operands, saturating: the default; holds 1e-3 against the fp32 network
+                                (network.hpp:117-123) on peaked, trained-network-like outputs too */
+#define AZ_PREC_BF16     1   /* bf16 operands: same MFMA rate in cycles, ~4 % faster in wall time (lower power),
+                                8x coarser rounding: within 1e-3 only on flat (random-init) outputs */
 
 typedef struct az_ctx az_ctx;
 

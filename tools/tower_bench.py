@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--precision", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16"], default="fp16")
     a = ap.parse_args()
     import torch
     from alphazero_amd import capi, synth
