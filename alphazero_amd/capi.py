@@ -45,7 +45,7 @@ class AzStats(C.Structure):
     _fields_ = [
         ("sims", C.c_int64), ("evals", C.c_int64), ("rounds", C.c_int64), ("moves", C.c_int64),
         ("games", C.c_int64), ("replay_rows", C.c_int64), ("replay_dropped", C.c_int64),
-        ("max_nodes", C.c_int32), ("max_edges", C.c_int32), ("error_games", C.c_int32), ("reserved", C.c_int32),
+        ("max_nodes", C.c_int32), ("max_edges", C.c_int32), ("error_games", C.c_int32), ("tree_restarts", C.c_int32),
         ("sims_backed_up", C.c_int64), ("descents", C.c_int64), ("tree_levels", C.c_int64),
         ("children_scanned", C.c_int64), ("children_expanded", C.c_int64),
     ]

@@ -6,6 +6,7 @@
 #include "az_rules.h"
 #include "az_tower.h"
 #include "az_tree.h"
+#include "az_weights.h"
 
 #include <algorithm>
 #include <cmath>
@@ -51,10 +52,12 @@ struct az_ctx {
     float* head_p = nullptr;
     float* head_pt = nullptr;                             // fused path: 1x1 weights as {policy, value} pairs, fc1 transposed [A][64]
     size_t conv_layer_elems = 0;
+    float* blob_stage = nullptr;                          // the fp32 blob as loaded, input of the fold kernels
     uint8_t* tower_in = nullptr;                          // staging for az_tower_forward [Bmax][3][A]
     float *tower_pol = nullptr, *tower_val = nullptr;
     // misc device scratch
     int* d_actions = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; int* d_illegal = nullptr;
+    uint8_t* d_export = nullptr;                          // [G][3][A] planes or [G][A] mask of az_env_boards / az_env_legal_mask
     int mode = AZ_MODE_SEARCH;
     bool search_active = false;
     int64_t rounds = 0;
@@ -183,6 +186,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     }
     AZCHK(dalloc(c, &c->d_actions, G)); AZCHK(dalloc(c, &c->d_reward, 2 * (size_t)G));
     AZCHK(dalloc(c, &c->d_done, G)); AZCHK(dalloc(c, &c->d_illegal, 4));
+    AZCHK(dalloc(c, &c->d_export, (size_t)G * 3 * A));
     if (az_tree_configure(&d) != 0) return fail(AZ_E_HIP, "tree kernel LDS configuration failed (node_cap %d)", d.node_cap);
 
     c->Bmax = (int)S;
@@ -211,6 +215,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
             AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
             AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
         }
+        AZCHK(dalloc(c, &c->blob_stage, weights_size(N, 3, cfg->Cs, cfg->n_Cs), false));
         AZCHK(dalloc(c, &c->tower_in, (size_t)c->Bmax * 3 * A));
         AZCHK(dalloc(c, &c->tower_pol, (size_t)c->Bmax * A)); AZCHK(dalloc(c, &c->tower_val, 2 * (size_t)c->Bmax));
         if (az_tower_configure() != 0) return fail(AZ_E_HIP, "tower kernel LDS configuration failed");
@@ -241,160 +246,66 @@ extern "C" size_t az_weights_size(const az_ctx* c) {
     return weights_size(c->cfg.N, 3, c->cfg.Cs, c->cfg.n_Cs);
 }
 
-static inline unsigned short host_f2bf(float x) {
-    unsigned u; memcpy(&u, &x, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
-// fp32 -> fp16 bits, round to nearest even, saturating at +-65504
-static inline unsigned short host_f2h(float x) {
-    if (x > 65504.f) x = 65504.f;
-    if (x < -65504.f) x = -65504.f;
-    unsigned u; memcpy(&u, &x, 4);
-    const unsigned sign = (u >> 16) & 0x8000u;
-    const int e = (int)((u >> 23) & 0xFF) - 127 + 15;
-    unsigned m = u & 0x7FFFFFu;
-    if (e <= 0) {                                   // subnormal or zero
-        if (e < -10) return (unsigned short)sign;
-        m |= 0x800000u;
-        const int shift = 14 - e;
-        unsigned hm = m >> shift;
-        const unsigned rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
-        if (rem > half || (rem == half && (hm & 1u))) ++hm;
-        return (unsigned short)(sign | hm);
-    }
-    unsigned h = ((unsigned)e << 10) | (m >> 13);
-    const unsigned rem = m & 0x1FFFu;
-    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
-    return (unsigned short)(sign | h);
-}
-
-// BatchNorm (eval, eps 1e-5: network.hpp:13,29-30,71) folded into the preceding
-// convolution in double; 3x3 kernels re-laid as [nb][sc][tap][kc][n][k] chunks.
-extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
-    NEED(c); NEED(blob);
-    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
-    if (n_floats != az_weights_size(c)) return fail(AZ_E_ARG, "blob has %zu floats, expected %zu", n_floats, az_weights_size(c));
-    HIPCHK(hipSetDevice(c->cfg.device));
-    // the uploads below are blocking copies that do not order against the context's (non-blocking)
-    // stream: let every launch that still reads the old weights finish first
+// load_network (util.h:60-105) minus the file: the blob is staged on the device, validated there, and
+// folded / packed by the kernels of weights.hip on the context's stream -- in stream order with the
+// evaluator launches, so weights can be swapped between two rounds of a running self-play.
+static int load_weights_staged(az_ctx* c) {
+    const int N = c->cfg.N, A = N * N, C = c->C;
+    AzFoldArgs a;
+    memset(&a, 0, sizeof a);
+    a.blob = c->blob_stage; a.n_floats = az_weights_size(c);
+    a.N = N; a.A = A; a.C = C; a.Cp = c->C_pad; a.nres = c->num_res;
+    a.fused = c->fused ? 1 : 0; a.prec = c->prec;
+    size_t o = 0;                                            // module registration order: CBlock, PHead, VHead, RBlock_i
+    a.off_stem_w = o; o += (size_t)C * 27 + C;
+    a.off_stem_bn = o; o += 4 * (size_t)C;
+    a.off_pc = o; o += (size_t)C + 1;
+    a.off_vc = o; o += (size_t)C + 1;
+    a.off_vbn = o; o += 4;
+    a.off_fc1 = o; o += (size_t)64 * A + 64 + 128 + 2;
+    a.off_res0 = o; a.res_stride = 2 * ((size_t)9 * C * C + C) + 8 * (size_t)C;
+    if (o + (size_t)c->num_res * a.res_stride != a.n_floats) return fail(AZ_E_STATE, "blob layout does not add up");
+    a.stem_w = c->stem_w; a.stem_b = c->stem_b; a.stem_wbf = c->stem_wbf; a.conv_wf = c->conv_wf; a.conv_w = c->conv_w;
+    a.conv_layer_elems = c->conv_layer_elems; a.conv_b = c->conv_b; a.head_p = c->head_p; a.head_pt = c->head_pt;
+    // validate before anything is overwritten: a bad blob leaves the current weights in place
+    HIPCHK(hipMemsetAsync(c->d_illegal, 0, 16, c->stream));
+    az_launch_check_blob(c->stream, &a, c->d_illegal);
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, c->d_illegal, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int N = c->cfg.N, A = N * N, C = c->C, Cp = c->C_pad, nres = c->num_res;
-    auto to16 = [c](float x) { return c->prec == 1 ? host_f2h(x) : host_f2bf(x); };
-    const float* p = blob;
-    struct Conv { const float *w, *b; };
-    struct Bn { const float *g, *b, *rm, *rv; };
-    auto conv = [&](size_t ci, size_t co, size_t k) { Conv r{p, p + co * ci * k * k}; p += co * ci * k * k + co; return r; };
-    auto bn = [&](size_t ch) { Bn r{p, p + ch, p + 2 * ch, p + 3 * ch}; p += 4 * ch; return r; };
-    const Conv stem = conv(3, C, 3); const Bn stem_bn = bn(C);
-    const Conv pc = conv(C, 1, 1);
-    const Conv vc = conv(C, 1, 1); const Bn vbn = bn(1);
-    const float* fc1w = p; p += (size_t)64 * A; const float* fc1b = p; p += 64;
-    const float* fc2w = p; p += 128; const float* fc2b = p; p += 2;
-    std::vector<Conv> c1(nres), c2(nres); std::vector<Bn> b1(nres), b2(nres);
-    for (int i = 0; i < nres; ++i) { c1[i] = conv(C, C, 3); c2[i] = conv(C, C, 3); b1[i] = bn(C); b2[i] = bn(C); }
-
-    auto scale = [](const Bn& b, int ch) { return (double)b.g[ch] / std::sqrt((double)b.rv[ch] + 1e-5); };
-    // stem: fp32 [Cp][27]
-    std::vector<float> sw((size_t)Cp * 27, 0.f), sb(Cp, 0.f);
-    for (int co = 0; co < C; ++co) {
-        const double s = scale(stem_bn, co);
-        for (int k = 0; k < 27; ++k) sw[(size_t)co * 27 + k] = (float)(stem.w[(size_t)co * 27 + k] * s);
-        sb[co] = (float)(((double)stem.b[co] - stem_bn.rm[co]) * s + stem_bn.b[co]);
-    }
-    if (!c->fused) HIPCHK(hipMemcpy(c->stem_w, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->stem_b, sb.data(), sb.size() * 4, hipMemcpyHostToDevice));
-    if (c->fused) {
-        std::vector<unsigned short> swb((size_t)128 * 32, 0);
-        for (int co = 0; co < C; ++co)
-            for (int k = 0; k < 27; ++k) swb[(size_t)co * 32 + k] = to16(sw[(size_t)co * 27 + k]);
-        HIPCHK(hipMemcpy(c->stem_wbf, swb.data(), swb.size() * 2, hipMemcpyHostToDevice));
-    }
-    // residual convolutions
-    const int nblk = Cp / 128;
-    std::vector<unsigned short> pk(c->fused ? 0 : c->conv_layer_elems * 2 * nres, 0);
-    std::vector<float> cb((size_t)2 * nres * Cp, 0.f);
-    for (int L = 0; L < 2 * nres; ++L) {
-        const Conv& cv = (L & 1) ? c2[L / 2] : c1[L / 2];
-        const Bn& bb = (L & 1) ? b2[L / 2] : b1[L / 2];
-        unsigned short* dst = pk.data() + (c->fused ? 0 : (size_t)L * c->conv_layer_elems);
-        for (int co = 0; co < C; ++co) {
-            const double s = scale(bb, co);
-            cb[(size_t)L * Cp + co] = (float)(((double)cv.b[co] - bb.rm[co]) * s + bb.b[co]);
-            if (c->fused) continue;
-            const int nb = co / 128, n = co % 128;
-            for (int ci = 0; ci < C; ++ci) {
-                const int sc = ci / 128, k = ci % 128;
-                for (int tap = 0; tap < 9; ++tap) {
-                    const size_t chunk = ((size_t)nb * nblk + sc) * 9 + tap;     // [nb][sc][tap][n][k]
-                    dst[chunk * (128 * 128) + (size_t)n * 128 + k] =
-                        to16((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
-                }
-            }
-        }
-    }
-    if (!c->fused) HIPCHK(hipMemcpy(c->conv_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
-    if (c->fused) {                               // one 32 KB chunk per tap: [layer][tap][n][k]
-        std::vector<unsigned short> pf((size_t)2 * nres * 9 * 128 * 128, 0);
-        for (int L = 0; L < 2 * nres; ++L) {
-            const Conv& cv = (L & 1) ? c2[L / 2] : c1[L / 2];
-            const Bn& bb = (L & 1) ? b2[L / 2] : b1[L / 2];
-            for (int co = 0; co < C; ++co) {
-                const double s = scale(bb, co);
-                for (int ci = 0; ci < C; ++ci)
-                    for (int tap = 0; tap < 9; ++tap)
-                        pf[(((size_t)L * 9 + tap) * 128 + co) * 128 + ci] =
-                            to16((float)(cv.w[((size_t)co * C + ci) * 9 + tap] * s));
-            }
-        }
-        HIPCHK(hipMemcpy(c->conv_wf, pf.data(), pf.size() * 2, hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpy(c->conv_b, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
-    // heads
-    std::vector<float> hp((size_t)2 * Cp + 2 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
-    const double vs = scale(vbn, 0);
-    for (int ch = 0; ch < C; ++ch) { hp[ch] = pc.w[ch]; hp[Cp + ch] = (float)(vc.w[ch] * vs); }
-    hp[2 * Cp] = pc.b[0];
-    hp[2 * Cp + 1] = (float)(((double)vc.b[0] - vbn.rm[0]) * vs + vbn.b[0]);
-    float* q = hp.data() + 2 * Cp + 2;
-    memcpy(q, fc1w, sizeof(float) * 64 * A); q += 64 * A;
-    memcpy(q, fc1b, sizeof(float) * 64); q += 64;
-    memcpy(q, fc2w, sizeof(float) * 128); q += 128;
-    memcpy(q, fc2b, sizeof(float) * 2);
-    if (!c->fused) HIPCHK(hipMemcpy(c->head_p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
-    if (c->fused) {
-        std::vector<float> ht((size_t)258 + 64 * (size_t)A + 64 + 128 + 2, 0.f);
-        for (int ch = 0; ch < C; ++ch) { ht[2 * ch] = hp[ch]; ht[2 * ch + 1] = hp[Cp + ch]; }   // {policy, value} pairs
-        ht[256] = hp[2 * Cp]; ht[257] = hp[2 * Cp + 1];
-        for (int o = 0; o < 64; ++o)
-            for (int a2 = 0; a2 < A; ++a2) ht[258 + (size_t)a2 * 64 + o] = fc1w[(size_t)o * A + a2];
-        float* q2 = ht.data() + 258 + 64 * (size_t)A;
-        memcpy(q2, fc1b, sizeof(float) * 64); q2 += 64;
-        memcpy(q2, fc2w, sizeof(float) * 128); q2 += 128;
-        memcpy(q2, fc2b, sizeof(float) * 2);
-        HIPCHK(hipMemcpy(c->head_pt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
-    }
+    if (bad & 1) return fail(AZ_E_ARG, "weight blob holds non-finite values");
+    if (bad & 2) return fail(AZ_E_ARG, "weight blob has a BatchNorm running_var + 1e-5 <= 0: its channel cannot be folded");
+    az_launch_fold(c->stream, &a);                           // padding entries of the images stay at their initial zero
+    HIPCHK(hipGetLastError());
     c->have_weights = true;
     return AZ_OK;
 }
 
-extern "C" int az_load_weights_dev(az_ctx* c, const float* blob_dev, size_t n_floats) {
-    NEED(c); NEED(blob_dev);
+static int load_weights_common(az_ctx* c, const float* blob, size_t n_floats, hipMemcpyKind kind) {
+    NEED(c); NEED(blob);
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
     if (n_floats != az_weights_size(c)) return fail(AZ_E_ARG, "blob has %zu floats, expected %zu", n_floats, az_weights_size(c));
-    std::vector<float> h(n_floats);
     HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipMemcpy(h.data(), blob_dev, n_floats * 4, hipMemcpyDeviceToHost));
-    return az_load_weights(c, h.data(), n_floats);
+    HIPCHK(hipMemcpyAsync(c->blob_stage, blob, n_floats * 4, kind, c->stream));
+    return load_weights_staged(c);                           // synchronises the stream: the caller's blob is free on return
+}
+
+extern "C" int az_load_weights(az_ctx* c, const float* blob, size_t n_floats) {
+    return load_weights_common(c, blob, n_floats, hipMemcpyHostToDevice);
+}
+
+// The blob already on this GPU (after an RCCL broadcast): nothing crosses PCIe.  The caller makes sure the
+// blob is complete (its producer's stream synchronised) before the call.
+extern "C" int az_load_weights_dev(az_ctx* c, const float* blob_dev, size_t n_floats) {
+    return load_weights_common(c, blob_dev, n_floats, hipMemcpyDeviceToDevice);
 }
 
 // ------------------------------------------------------------------- tower
-static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev) {
-    if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
-    if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
+// actX / actH: the two activation images of the per-layer path ([guard + M_pad + guard][C_pad] 16-bit rows,
+// guard and padding rows zero); unused by the fused kernel, whose activations never leave LDS.
+static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev,
+                        unsigned short* actX, unsigned short* actH, bool sampled) {
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
-    const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled, c->stream);
         az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
@@ -403,20 +314,27 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
-    az_launch_stem(c->stream, c->prec, planes_dev, c->actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
+    az_launch_stem(c->stream, c->prec, planes_dev, actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
         bool on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->actX, c->actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
         on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->actH, c->actX, c->actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, actH, actX, actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
     }
-    az_launch_heads(c->stream, c->prec, c->actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+    az_launch_heads(c->stream, c->prec, actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
     HIPCHK(hipGetLastError());
     return AZ_OK;
+}
+
+static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev) {
+    if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
+    if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
+    const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
+    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, sampled);
 }
 
 extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
@@ -468,8 +386,8 @@ extern "C" int az_env_step(az_ctx* c, const int32_t* actions, float* reward, uin
 extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
     NEED(c); NEED(planes);
     HIPCHK(hipSetDevice(c->cfg.device));
-    az_launch_env_export(c->stream, &c->d, c->d.leaf_planes, nullptr);
-    HIPCHK(hipMemcpyAsync(planes, c->d.leaf_planes, (size_t)c->cfg.G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
+    az_launch_env_export(c->stream, &c->d, c->d_export, nullptr);       // own scratch: never the evaluator's live input
+    HIPCHK(hipMemcpyAsync(planes, c->d_export, (size_t)c->cfg.G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
 }
@@ -477,9 +395,8 @@ extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
 extern "C" int az_env_legal_mask(az_ctx* c, uint8_t* mask) {
     NEED(c); NEED(mask);
     HIPCHK(hipSetDevice(c->cfg.device));
-    // borrow the first G*A bytes of the row staging area
-    az_launch_env_export(c->stream, &c->d, nullptr, c->d.row_tomove);
-    HIPCHK(hipMemcpyAsync(mask, c->d.row_tomove, (size_t)c->cfg.G * c->A, hipMemcpyDeviceToHost, c->stream));
+    az_launch_env_export(c->stream, &c->d, nullptr, c->d_export);
+    HIPCHK(hipMemcpyAsync(mask, c->d_export, (size_t)c->cfg.G * c->A, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
 }
@@ -595,16 +512,24 @@ static int check_errors(az_ctx* c) {
     std::vector<int> err(c->cfg.G);
     HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * c->cfg.G, hipMemcpyDeviceToHost));
     for (int g = 0; g < c->cfg.G; ++g)
-        if (err[g] == 1) return fail(AZ_E_CAPACITY, "game %d: tree arena full (node_cap %d); raise az_config.node_cap", g, c->d.node_cap);
-        else if (err[g]) return fail(AZ_E_STATE, "game %d: no selectable child (mcts.hpp:374-375)", g);
+        if (err[g]) return fail(AZ_E_STATE, "game %d: no selectable child (mcts.hpp:374-375)", g);
+    return AZ_OK;
+}
+
+// A search from a fresh root expands at most one node per simulation plus the root; self-play searches a new
+// game's root twice (warm-up, generate.cpp:77).  An arena that cannot hold that would restart for ever.
+static int check_budget(az_ctx* c, int budget, int searches_per_root) {
+    const long long need = (long long)searches_per_root * (budget > 1 ? budget : 1) + 2;
+    if (need > c->d.node_cap)
+        return fail(AZ_E_ARG, "budget %d needs %lld tree nodes per game, the arena holds %d (az_config.node_cap / max_budget)",
+                    budget, need, c->d.node_cap);
     return AZ_OK;
 }
 
 extern "C" int az_search_begin(az_ctx* c, int budget) {
     NEED(c);
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
-        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget (arena sized for %d nodes)", budget, c->d.node_cap);
+    AZCHK(check_budget(c, budget, 1));
     c->mode = AZ_MODE_SEARCH;
     az_launch_begin(c->stream, &c->d, budget);
     HIPCHK(hipGetLastError());
@@ -625,16 +550,17 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
         if (r < rounds - 1) AZCHK(run_evaluator(c));
         c->rounds++;
     }
-    // with L > 1 a round can issue fewer than L descents (two of them met at one stub):
-    // keep going until every game reports its search finished
+    // a search can need more rounds than that: with L > 1 a round issues fewer than L descents when two of
+    // them meet at one stub, and a tree whose arena filled up starts over from a fresh root.  Keep going
+    // until every game reports its search finished.
     std::vector<int> st(c->cfg.G);
-    for (int extra = 0; c->d.L > 1; ++extra) {
+    for (int extra = 0;; ++extra) {
         HIPCHK(hipMemcpyAsync(st.data(), c->d.status, sizeof(int) * c->cfg.G, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         bool running = false;
         for (int x : st) running = running || x == AZ_ST_RUN;
         if (!running) break;
-        if (extra > b + 2) return fail(AZ_E_STATE, "search did not finish within its round bound");
+        if (extra > 4 * (b + 2)) return fail(AZ_E_STATE, "search did not finish within its round bound");
         for (int r = 0; r < 4; ++r) {
             AZCHK(run_evaluator(c));
             az_launch_round(c->stream, &c->d, 3, AZ_MODE_SEARCH, 0, c->cfg.G);
@@ -742,8 +668,7 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     NEED(c);
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "self-play needs a device evaluator");
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (c->cfg.node_cap == 0 && 4 * budget + 64 > c->d.node_cap)
-        return fail(AZ_E_ARG, "budget %d exceeds az_config.max_budget (arena sized for %d nodes)", budget, c->d.node_cap);
+    AZCHK(check_budget(c, budget, 2));
     c->d.budget = budget > 1 ? budget : 1;
     c->mode = AZ_MODE_SELFPLAY;
     HIPCHK(hipMemsetAsync(c->d.counters, 0, 16 * sizeof(unsigned long long), c->stream));
@@ -835,6 +760,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
         s->evals += (int64_t)q[AZ_GC_EVALS]; s->descents += (int64_t)q[AZ_GC_DESCENTS];
         s->tree_levels += (int64_t)q[AZ_GC_LEVELS]; s->children_scanned += (int64_t)q[AZ_GC_SCANNED];
         s->children_expanded += (int64_t)q[AZ_GC_EXPANDED];
+        s->tree_restarts += (int32_t)q[AZ_GC_RESTARTS];
         if (st[g] == AZ_ST_RUN) s->sims_backed_up += sd[g];
         s->max_nodes = std::max(s->max_nodes, std::max(hn[g], nn[g]));
         s->max_edges = std::max(s->max_edges, std::max(he[g], ne[g]));

@@ -1,0 +1,113 @@
+// weights.hip -- device-side weight preparation: the flat fp32 blob (module registration order of
+// network.hpp:106-114, as torch::save walks it) -> the images the tower kernels read.  Eval-mode
+// BatchNorm (eps 1e-5, network.hpp:13,29-30,71) is folded into the preceding convolution in double,
+// 3x3 kernels are re-laid per tap and rounded to the MFMA operand format.  Everything runs on the
+// context's stream, so a blob that arrived by an RCCL broadcast never visits the host and a swap
+// between two evaluator launches needs no synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "az_weights.h"
+
+__device__ __forceinline__ unsigned short w_to16(float x, int prec) {
+    if (prec == 1) {                                          // fp16, saturating, round to nearest even
+        x = fminf(fmaxf(x, -65504.f), 65504.f);
+        const _Float16 h = (_Float16)x;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    unsigned u = __float_as_uint(x);                          // bf16, round to nearest even
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ double bn_scale(const float* bn, int C, int ch) {     // bn: weight, bias, mean, var
+    return (double)bn[ch] / sqrt((double)bn[3 * C + ch] + 1e-5);
+}
+__device__ __forceinline__ float bn_bias(const float* bn, int C, int ch, float conv_bias, double s) {
+    return (float)(((double)conv_bias - bn[2 * C + ch]) * s + bn[C + ch]);
+}
+
+// Every value finite, every running_var + eps positive (a fold through sqrt of a negative number would
+// silently kill the channel).  bad: bit 0 non-finite value, bit 1 non-positive variance.
+__global__ void az_check_blob_kernel(AzFoldArgs a, int* bad) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int flag = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_floats; i += stride)
+        if (!isfinite(a.blob[i])) flag |= 1;
+    const int n_bn = 2 * a.nres + 1;                          // stem bn, then bn1/bn2 of every block
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_bn * a.C + 1; i += stride) {
+        float rv;
+        if (i == (size_t)n_bn * a.C) rv = a.blob[a.off_vbn + 3];
+        else {
+            const int b = (int)(i / a.C), ch = (int)(i % a.C);
+            const size_t base = b == 0 ? a.off_stem_bn
+                                       : a.off_res0 + (size_t)((b - 1) >> 1) * a.res_stride + 2 * ((size_t)9 * a.C * a.C + a.C) + (size_t)((b - 1) & 1) * 4 * a.C;
+            rv = a.blob[base + 3 * (size_t)a.C + ch];
+        }
+        if (!((double)rv + 1e-5 > 0.0)) flag |= 2;
+    }
+    if (flag) atomicOr(bad, flag);
+}
+
+// grid (2 * nres, C): one block per (convolution, output channel); threads stride its C * 9 weights.
+__global__ void __launch_bounds__(256) az_fold_conv_kernel(AzFoldArgs a) {
+    const int L = blockIdx.x, co = blockIdx.y, C = a.C;
+    const size_t wsz = (size_t)9 * C * C + C;
+    const float* blk = a.blob + a.off_res0 + (size_t)(L >> 1) * a.res_stride;
+    const float* w = blk + (size_t)(L & 1) * wsz;
+    const float* bn = blk + 2 * wsz + (size_t)(L & 1) * 4 * C;
+    const double s = bn_scale(bn, C, co);
+    if (threadIdx.x == 0) a.conv_b[(size_t)L * a.Cp + co] = bn_bias(bn, C, co, w[(size_t)9 * C * C + co], s);
+    const int nblk = a.Cp / 128;
+    for (int e = threadIdx.x; e < C * 9; e += 256) {
+        const int ci = e / 9, tap = e % 9;
+        const unsigned short v = w_to16((float)(w[(size_t)co * C * 9 + e] * s), a.prec);
+        if (a.fused)                                          // one 32 KB chunk per tap: [layer][tap][n][k]
+            a.conv_wf[(((size_t)L * 9 + tap) * 128 + co) * 128 + ci] = v;
+        else {                                                // [layer][nb][sc][tap][n][k]
+            const size_t chunk = ((size_t)(co / 128) * nblk + ci / 128) * 9 + tap;
+            a.conv_w[(size_t)L * a.conv_layer_elems + chunk * (128 * 128) + (size_t)(co % 128) * 128 + ci % 128] = v;
+        }
+    }
+}
+
+// Stem and heads: one block.
+__global__ void __launch_bounds__(256) az_fold_small_kernel(AzFoldArgs a) {
+    const int C = a.C, Cp = a.Cp, A = a.A;
+    const float* sw = a.blob + a.off_stem_w;
+    const float* sb = sw + (size_t)C * 27;
+    const float* sbn = a.blob + a.off_stem_bn;
+    for (int e = threadIdx.x; e < C * 27; e += 256) {
+        const int co = e / 27, k = e % 27;
+        const float f = (float)(sw[e] * bn_scale(sbn, C, co));
+        if (a.fused) a.stem_wbf[(size_t)co * 32 + k] = w_to16(f, a.prec);
+        else a.stem_w[e] = f;
+    }
+    for (int co = threadIdx.x; co < C; co += 256) a.stem_b[co] = bn_bias(sbn, C, co, sb[co], bn_scale(sbn, C, co));
+    // heads: policy 1x1 as is; value 1x1 with its one-channel BatchNorm folded
+    const float* pc = a.blob + a.off_pc;                      // w[C], b
+    const float* vc = a.blob + a.off_vc;                      // w[C], b
+    const float* vbn = a.blob + a.off_vbn;                    // weight, bias, mean, var
+    const double vs = bn_scale(vbn, 1, 0);
+    const float* fc1w = a.blob + a.off_fc1;                   // [64][A], then fc1b[64], fc2w[2][64], fc2b[2]
+    const float bvf = bn_bias(vbn, 1, 0, vc[C], vs);
+    if (a.fused) {
+        float* ht = a.head_pt;                                // {policy, value} weight pairs, biases at [256], [257]
+        for (int ch = threadIdx.x; ch < C; ch += 256) { ht[2 * ch] = pc[ch]; ht[2 * ch + 1] = (float)(vc[ch] * vs); }
+        if (threadIdx.x == 0) { ht[256] = pc[C]; ht[257] = bvf; }
+        for (int e = threadIdx.x; e < 64 * A; e += 256) ht[258 + (size_t)(e % A) * 64 + e / A] = fc1w[e];   // fc1 transposed [A][64]
+        for (int e = threadIdx.x; e < 64 + 128 + 2; e += 256) ht[258 + (size_t)64 * A + e] = fc1w[(size_t)64 * A + e];
+    } else {
+        float* hp = a.head_p;                                 // wp[Cp], wv[Cp], bp, bv, fc1w [64][A], fc1b, fc2w, fc2b
+        for (int ch = threadIdx.x; ch < C; ch += 256) { hp[ch] = pc[ch]; hp[Cp + ch] = (float)(vc[ch] * vs); }
+        if (threadIdx.x == 0) { hp[2 * Cp] = pc[C]; hp[2 * Cp + 1] = bvf; }
+        for (int e = threadIdx.x; e < 64 * A + 64 + 128 + 2; e += 256) hp[2 * Cp + 2 + e] = fc1w[e];
+    }
+}
+
+extern "C" void az_launch_check_blob(hipStream_t s, const AzFoldArgs* a, int* bad) {
+    hipLaunchKernelGGL(az_check_blob_kernel, dim3(1024), dim3(256), 0, s, *a, bad);
+}
+extern "C" void az_launch_fold(hipStream_t s, const AzFoldArgs* a) {
+    hipLaunchKernelGGL(az_fold_conv_kernel, dim3(2 * a->nres, a->C), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(az_fold_small_kernel, dim3(1), dim3(256), 0, s, *a);
+}

@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     agent.clear();
     // PVNetwork shim
     az::PVNetwork net(3, az::NetConfig::get(2).resblocks(), 3, 1);
-    std::vector<float> blob = az::random_blob(net->weights_size(), 1);
+    std::vector<float> blob = az::fresh_blob(3, 3, az::NetConfig::get(2).resblocks(), 1);
     net->load_blob(blob.data(), blob.size());
     az::ByteTensor x({2, 3, 3, 3});
     x.v[4] = 1;

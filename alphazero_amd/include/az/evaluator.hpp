@@ -32,7 +32,7 @@ public:
         bool changed = false;
         const std::string path = load_network(w, model_path, changed, [this](WeightFile& f) {
             f.N = Env::N; f.c_in = 3; f.c_out = 1; f.Cs = NetConfig::get(2).resblocks();
-            f.blob = random_blob(az_weights_size(ctx), 0);
+            f.blob = fresh_blob(Env::N, 3, f.Cs, 0);
         });
         if (changed) {
             if (w.N != Env::N || w.Cs != NetConfig::get(2).resblocks()) throw Error("checkpoint shape does not match the environment");

@@ -52,7 +52,7 @@ public:
         bool changed = false;
         const std::string path = load_network(w, model_path, changed, [this](WeightFile& f) {
             f.N = Env::N; f.c_in = 3; f.c_out = 1; f.Cs = NetConfig::get(2).resblocks();
-            f.blob = random_blob(az_weights_size(ctxs[0]), 0);
+            f.blob = fresh_blob(Env::N, 3, f.Cs, 0);
         });
         if (changed) {
             for (az_ctx* c : ctxs) check(az_load_weights(c, w.blob.data(), w.blob.size()));
@@ -100,7 +100,7 @@ public:
             check(az_get_stats(c, &s));
             t.sims += s.sims; t.evals += s.evals; t.moves += s.moves; t.games += s.games;
             t.replay_rows += s.replay_rows; t.replay_dropped += s.replay_dropped;
-            t.error_games += s.error_games; t.sims_backed_up += s.sims_backed_up;
+            t.error_games += s.error_games; t.tree_restarts += s.tree_restarts; t.sims_backed_up += s.sims_backed_up;
             t.descents += s.descents; t.tree_levels += s.tree_levels;
             t.children_scanned += s.children_scanned; t.children_expanded += s.children_expanded;
             t.rounds = s.rounds > t.rounds ? s.rounds : t.rounds;

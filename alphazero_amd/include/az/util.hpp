@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -54,13 +55,32 @@ inline void write_azw(const std::string& path, const WeightFile& w) {
     f.write((const char*)w.blob.data(), (std::streamsize)(n * 4));
 }
 
-// Fresh random weights in blob order (the reference saves a freshly constructed
-// network when the named file is missing, util.h:94-97).
-inline std::vector<float> random_blob(size_t n, uint32_t seed) {
+// A freshly constructed network in blob order (the reference saves one when the named file is missing,
+// util.h:94-97): module registration order CBlock, PHead, VHead, RBlock_i (network.hpp:106-114) with torch's
+// default initialisation -- convolutions and linear layers U(+-1/sqrt(fan_in)) for weight and bias, BatchNorm
+// weight 1, bias 0, running_mean 0, running_var 1.
+inline std::vector<float> fresh_blob(int N, int c_in, const std::vector<int>& Cs, uint32_t seed) {
     std::mt19937 g(seed);
-    std::uniform_real_distribution<float> u(-0.05f, 0.05f);
-    std::vector<float> b(n);
-    for (auto& x : b) x = u(g);
+    std::vector<float> b;
+    auto uniform = [&](size_t n, size_t fan_in) {
+        const float k = 1.0f / std::sqrt((float)fan_in);
+        std::uniform_real_distribution<float> u(-k, k);
+        for (size_t i = 0; i < n; ++i) b.push_back(u(g));
+    };
+    auto conv = [&](size_t ci, size_t co, size_t ks) { uniform(co * ci * ks * ks, ci * ks * ks); uniform(co, ci * ks * ks); };
+    auto linear = [&](size_t in, size_t out) { uniform(out * in, in); uniform(out, in); };
+    auto bn = [&](size_t ch) {
+        b.insert(b.end(), ch, 1.0f); b.insert(b.end(), ch, 0.0f);       // weight, bias
+        b.insert(b.end(), ch, 0.0f); b.insert(b.end(), ch, 1.0f);       // running_mean, running_var
+    };
+    const size_t num_res = Cs.size() - 1, Ch = (size_t)Cs[num_res - 1], A = (size_t)N * N;
+    conv((size_t)c_in, (size_t)Cs[0], 3); bn((size_t)Cs[0]);
+    conv(Ch, 1, 1);                                                   // PHead
+    conv(Ch, 1, 1); bn(1); linear(A, 64); linear(64, 2);              // VHead
+    for (size_t i = 0; i < num_res; ++i) {
+        conv((size_t)Cs[i], (size_t)Cs[i + 1], 3); conv((size_t)Cs[i + 1], (size_t)Cs[i + 1], 3);
+        bn((size_t)Cs[i + 1]); bn((size_t)Cs[i + 1]);
+    }
     return b;
 }
 
@@ -94,7 +114,14 @@ inline std::string load_network(WeightFile& w, const std::string& current, bool&
     if (read_azw(export_path + ".azw", w) || read_azw(export_path, w)) {
         std::cout << "Network loaded.\nPath: " << export_path << std::endl;
     } else if (std::ifstream(export_path).good()) {
-        throw Error("checkpoint " + export_path + " is a libtorch archive: convert it with tools/pt2blob.py first");
+        // the trainer published a libtorch archive (util.h:108-139) and its flat-blob twin <path>.azw
+        // (tools/pt2blob.py, one-shot or --watch) is not there yet: keep playing with the weights in
+        // use and look again at the next load(), as a generator between two checkpoints would
+        if (current.empty())
+            throw Error("checkpoint " + export_path + " is a libtorch archive and " + export_path +
+                        ".azw does not exist: convert it with tools/pt2blob.py (or run it with --watch)");
+        std::cout << "Checkpoint " << export_path << " has no .azw twin yet. Resuming with network " << current << std::endl;
+        return current;
     } else {
         std::cout << "Model path provided by 'ckpt_location.txt' doesn't exist. Creating a new one." << std::endl;
         fresh(w);

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Self-play hot-path benchmark: MCTS simulations/s, whole job.
 
-One step = one lockstep round = one pass of the hot path (env step -> PUCT
-select -> tower evaluation -> expand -> backup) over G concurrent 15x15 gomoku
-games per GPU (BASELINE.json configs[2] sharded by game: 4096 games over 8
-GPUs = 512 per GPU; at N=1 the same 512-game shard).  Weak scaling: every rank
-owns its own games, there is no collective inside the timed region.
+One step = one move of the lockstep batch = `sims/move` passes of the hot path
+(env step -> PUCT select -> tower evaluation -> expand -> backup) over G
+concurrent 15x15 gomoku games per GPU, including the re-root that carries every
+tree over to the next move (BASELINE.json configs[2] sharded by game: 4096
+games over 8 GPUs = 512 per GPU; at N=1 the same 512-game shard).  Weak
+scaling: every rank owns its own games, there is no collective inside the
+timed region.
 
-    python bench.py --gpus 1 --steps 300 --warmup 40
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 """
 import argparse
@@ -64,8 +66,8 @@ def cpu_baseline(seconds, N, K, budget, nthreads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one move of every game = sims/move rounds")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the timed region")
     ap.add_argument("--games", type=int, default=512, help="concurrent games per GPU")
     ap.add_argument("--board", type=int, default=15)
     ap.add_argument("--budget", type=int, default=800)
@@ -151,17 +153,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # one step = one move's worth of lockstep rounds (sims/move descents per game, L per round)
+    rps = (budget + args.leaves - 1) // args.leaves
+    # HIP events around every `every`-th evaluator call and tree round of the timed region, within the
+    # library's event pool (4096 spans): every launch when the region is short
+    spans_per_round = 2 if Cs[0] <= 128 and N <= 15 else 2 * (len(Cs) - 1) + 1
+    every = max(1, -(-(args.steps * rps * spans_per_round) // 3600))
     for e in engs:
         e.selfplay_begin(budget)
-    run(args.warmup)
-    eng.profile_enable(8)
+    run(args.warmup * rps)
+    eng.profile_enable(every)
     barrier()
     TALLY = ("descents", "tree_levels", "children_scanned", "children_expanded", "evals")
     st0 = [e.stats() for e in engs]
     sims0 = sum(x["sims_backed_up"] for x in st0)
     tally0 = {k: sum(x[k] for x in st0) for k in TALLY}
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps * rps)
     barrier()
     el = time.perf_counter() - t0
     if use_dist:
@@ -187,7 +195,7 @@ def main():
         # whole games: keep the same engine running, count games finished per wall second
         eng.profile_enable(0)
         t1 = time.perf_counter()
-        g0, m0 = st["games"], st["moves"]
+        g0, m0, s0fg = st["games"], st["moves"], st["sims_backed_up"]
         while time.perf_counter() - t1 < args.full_games:
             run(budget)
             for e in engs:
@@ -195,19 +203,20 @@ def main():
         el2 = time.perf_counter() - t1
         sts2 = [e.stats() for e in engs]
         st2 = {k: sum(x[k] for x in sts2) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts2) for k in sts2[0]}
-        ng, nm = st2["games"] - g0, st2["moves"] - m0
+        ng, nm, ns = st2["games"] - g0, st2["moves"] - m0, st2["sims_backed_up"] - s0fg
         if use_dist:                                       # whole-job totals
-            t = torch.tensor([ng, nm], dtype=torch.int64, device="cuda")
+            t = torch.tensor([ng, nm, ns], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            ng, nm = int(t[0].item()), int(t[1].item())
+            ng, nm, ns = int(t[0].item()), int(t[1].item()), int(t[2].item())
             t = torch.tensor([el2], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
         games_info = {"seconds": el2, "games": ng, "moves": nm,
-                      "games_per_hour": ng / el2 * 3600.0,
+                      "games_per_hour": ng / el2 * 3600.0, "sims_per_s": ns / el2,
                       # finished games only: a lower bound on the rate while the first games are still running
                       "moves_per_s": nm / el2, "mean_game_length": nm / max(1, ng),
-                      "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"]}
+                      "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"],
+                      "tree_restarts": st2["tree_restarts"]}
 
     overlap = None
     if NC == 1 and not args.no_overlap_probe and G % 2 == 0:
@@ -226,11 +235,11 @@ def main():
             else:
                 e.load_weights(blob)
             e.selfplay_begin(budget)
-        run(args.warmup)
+        run(args.warmup * rps)
         barrier()
         s0 = sum(e.stats()["sims_backed_up"] for e in engs)
         t1 = time.perf_counter()
-        run(args.steps)
+        run(args.steps * rps)
         barrier()
         el2 = time.perf_counter() - t1
         s1 = sum(e.stats()["sims_backed_up"] for e in engs) - s0
@@ -242,6 +251,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             s1 = int(t.item())
         overlap = {"contexts_per_gpu": 2, "value": s1 / el2, "unit": "sims/s", "ms_per_step": el2 / args.steps * 1e3,
+                   "ms_per_round": el2 / (args.steps * rps) * 1e3,
                    "note": "same games as two contexts on two streams (bench.py --contexts 2): tree rounds run under the "
                            "other context's tower; informational, launches overlap so no per-launch roofline here"}
 
@@ -268,6 +278,8 @@ def main():
         line = {
             "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "step": "one move of every game: %d lockstep rounds (%d sims/move, %d per round), re-root included" % (rps, budget, args.leaves),
+            "rounds_per_step": rps, "ms_per_round": el / (args.steps * rps) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
                                    "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
@@ -290,7 +302,7 @@ def main():
         # policy and value (4A + 8 B) in; counted on the device (az_stats), rank 0's games, per launch.
         if tally["descents"] > 0 and prof["tree_avg_us"] > 0:
             tree_bytes = (12.0 * tally["children_scanned"] + 24.0 * tally["tree_levels"] + 16.0 * tally["children_expanded"]
-                          + tally["evals"] * (7.0 * A + 8.0)) / args.steps / NC
+                          + tally["evals"] * (7.0 * A + 8.0)) / (args.steps * rps) / NC
             tree_traffic = None
             if traffic is not None:
                 try:
@@ -305,6 +317,8 @@ def main():
                 "mean_depth": tally["tree_levels"] / tally["descents"],
                 "mean_children_per_level": tally["children_scanned"] / max(1, tally["tree_levels"]),
                 "note": "a chain of dependent loads, one per tree level: latency-bound, 512 one-wave blocks"}
+        line["consistency"] = {"timed_region_s": el, "rounds_timed": args.steps * rps, "profile_every": every,
+                               "sims_per_s_of_full_games_phase": games_info["sims_per_s"] if games_info else None}
         line["full_games"] = games_info
         line["two_context_overlap"] = overlap
         if world == 1 and not args.no_cpu_baseline:

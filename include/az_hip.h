@@ -29,7 +29,7 @@ extern "C" {
 #define AZ_OK            0
 #define AZ_E_ARG        -1   /* bad argument */
 #define AZ_E_HIP        -2   /* HIP runtime error (message has the call) */
-#define AZ_E_CAPACITY   -3   /* a tree arena overflowed */
+#define AZ_E_CAPACITY   -3   /* a capacity fixed at az_ctx_create is too small for the request */
 #define AZ_E_STATE      -4   /* call not valid in the current state */
 #define AZ_E_NOWEIGHTS  -5   /* tower used before az_load_weights */
 
@@ -59,7 +59,8 @@ typedef struct az_config {
     int   Cs[AZ_MAX_LAYERS];      /* NetConfig::resblocks() (netconfig.hpp:19-22) */
     float vl;                     /* MCTS ctor vl_ (mcts.hpp:41) */
     float c_puct;                 /* MCTS ctor c_puct_; truncated to int by Node::ucb (node.hpp:47) */
-    int   node_cap;               /* expanded nodes per tree arena, 0 = 4*max_budget+64 */
+    int   node_cap;               /* expanded nodes per tree arena, 0 = 4*max_budget+64; a tree that outgrows it is
+                                     dropped and its search restarts from a fresh root (az_stats.tree_restarts) */
     int   max_budget;             /* largest iter_budget that will be requested */
     int   eval_mode;
     int   noise_mode;
@@ -83,8 +84,9 @@ typedef struct az_stats {
     int64_t replay_dropped;       /* rows dropped because the ring was full */
     int32_t max_nodes;            /* high-water mark of expanded nodes in any tree */
     int32_t max_edges;
-    int32_t error_games;          /* games whose arena overflowed */
-    int32_t reserved;
+    int32_t error_games;          /* games stopped by an error (no selectable child, mcts.hpp:374-375) */
+    int32_t tree_restarts;        /* searches restarted from a fresh root because their arena was full (the
+                                     reference's heap has no cap; it does the same on a find() miss, mcts.hpp:392-414) */
     int64_t sims_backed_up;       /* simulations backed up so far, searches in flight included */
     /* what the tree kernel's memory traffic is made of (summed over games since the context's
      * creation or its last az_selfplay_begin): */

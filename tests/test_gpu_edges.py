@@ -86,13 +86,28 @@ def test_env_load_rejects_illegal_histories():
         eng.env_load([[0, 3, 1, 4, 2, 5]])              # move after a win
 
 
-def test_arena_overflow_is_reported_not_silently_truncated():
-    N, K, G = 7, 5, 2
-    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=64, node_cap=16)
+def test_arena_overflow_restarts_the_search_from_a_fresh_root():
+    """A tree that outgrows its arena is dropped and its search starts over from a fresh root (what
+    __make_root does on a find() miss, mcts.hpp:392-414): the slot keeps going, the event is counted."""
+    N, K, G, budget = 7, 5, 3, 64
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=budget, node_cap=budget + 6)
+    noise = np.stack([azo.dirichlet(70 + g, N * N)[0] for g in range(G)])
+    eng.set_noise(noise)
     eng.env_reset()
-    with pytest.raises(capi.AzError, match="arena full"):
-        eng.search(64)
-    with pytest.raises(capi.AzError, match="exceeds az_config.max_budget"):
+    first = eng.search(budget)                       # 65 nodes: fits
+    assert eng.stats()["tree_restarts"] == 0
+    again = eng.search(budget)                       # same root keeps accumulating (Q9) -> the arena fills -> restart
+    st = eng.stats()
+    assert st["tree_restarts"] == G and st["error_games"] == 0
+    assert np.array_equal(again, first)              # the restarted search is a fresh 64-simulation search
+    for g in range(G):
+        m = azo.MCTS(N, K, 3.0, 3.0, "hash")
+        assert np.array_equal(again[g], m.search([], budget, noise[g]))
+        assert eng.tree_canonical(g) == azo.canonical_tree(m.dump())
+    # an arena that cannot hold even one search is refused up front instead of restarting for ever
+    with pytest.raises(capi.AzError, match="tree nodes per game"):
+        capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=64, node_cap=16).search(64)
+    with pytest.raises(capi.AzError, match="tree nodes per game"):
         capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=8).search(4000)
 
 

@@ -121,6 +121,30 @@ def test_selfplay_rows_are_consistent_full_size():
     assert np.allclose(s[first], 2 * budget / (2 * budget + 1.0), atol=2e-5)
 
 
+def test_selfplay_survives_a_peaked_policy_at_full_size():
+    """15x15, 512 games, 800 sims/move with the heads sharpened 20x (a trained-network-like peaked policy:
+    most of a move's visits sit under the move played, so most of the tree is kept across moves and the
+    arena fills fastest).  At least 12 moves per slot: no slot may stop, and the default arena
+    (4 * budget + 64 nodes) must hold every tree without a restart."""
+    N, K, G, budget = 15, 5, 512, 800
+    Cs = synth.NETCONFIG2
+    eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=21)
+    eng.load_weights(synth.make_blob(N, 3, Cs, 0, phead_gain=20.0, fc2_gain=20.0))
+    eng.selfplay_begin(budget)
+    for _ in range(14):                                 # warm-up search + 13 moves' worth of rounds
+        eng.selfplay_run(budget + 2)
+    st = eng.stats()
+    print("peaked self-play:", {k: st[k] for k in ("moves", "games", "max_nodes", "max_edges", "tree_restarts", "error_games")})
+    assert st["error_games"] == 0
+    assert st["moves"] >= 12 * G
+    assert st["tree_restarts"] == 0
+    assert st["max_nodes"] < 4 * budget + 64
+    # every slot is still searching
+    assert eng.stats()["sims_backed_up"] > st["sims_backed_up"] - 1 and st["rounds"] == 14 * (budget + 2)
+    cells, tm, pol, rew = eng.replay_drain(1 << 16)
+    assert (pol[cells != 0] == 0).all()
+
+
 def test_run_selfplay_driver_two_contexts_single_rank():
     """alphazero_amd.selfplay.run_selfplay (the per-rank driver of the multi-GPU path) on one
     rank over RCCL: two engine contexts on two streams, rows gathered to the sink, slot ranges

@@ -206,3 +206,42 @@ def test_tower_requires_weights_and_uniform_widths():
         eng.tower_forward(synth.random_boards(2, 9))
     with pytest.raises(capi.AzError):
         capi.Engine(9, 5, 4, Cs=[128, 64, 32])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_weights_are_folded_on_the_device_and_bad_blobs_are_refused(monkeypatch, fused):
+    """az_load_weights_dev (the blob already on the GPU, as after an RCCL broadcast) gives the bits of
+    az_load_weights; a blob with a non-positive BatchNorm variance or a non-finite value is refused with
+    AZ_E_ARG and leaves the weights in use untouched."""
+    import torch
+    if not fused:
+        monkeypatch.setenv("AZ_NO_FUSED", "1")
+    N, B, Cs = 9, 6, synth.NETCONFIG2
+    blob = synth.make_blob(N, 3, Cs, 77, phead_gain=5.0)
+    boards = synth.random_boards(B, N, seed=77)
+    e1 = capi.Engine(N, 5, B, Cs=Cs)
+    assert e1.tower_is_fused() == fused
+    e1.load_weights(blob)
+    p1, v1 = e1.tower_forward(boards)
+    e2 = capi.Engine(N, 5, B, Cs=Cs)
+    t = torch.from_numpy(blob).cuda()
+    torch.cuda.synchronize()
+    e2.load_weights_dev(t.data_ptr(), blob.size)
+    p2, v2 = e2.tower_forward(boards)
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+    layout = synth.blob_layout(N, 3, Cs)
+    off = 0
+    for name, shape in layout:
+        if name == "RBlock_3.bn2.running_var":
+            break
+        off += int(np.prod(shape))
+    bad = blob.copy()
+    bad[off + 5] = -0.3                                  # sqrt of a negative variance
+    with pytest.raises(capi.AzError, match="running_var"):
+        e2.load_weights(bad)
+    bad = blob.copy()
+    bad[1234] = np.nan
+    with pytest.raises(capi.AzError, match="non-finite"):
+        e2.load_weights(bad)
+    p3, v3 = e2.tower_forward(boards)                    # the weights loaded before are still in place
+    assert np.array_equal(p3, p1) and np.array_equal(v3, v1)
