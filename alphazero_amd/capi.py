@@ -54,13 +54,52 @@ class AzStats(C.Structure):
 _lib = None
 
 
+def hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (/proc/self/maps)."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libamdhip64" in ln:
+                    paths.add(os.path.realpath(ln.split()[-1]))
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7; libazhip.so needs the same
+    soname and would otherwise pull in the system's (/opt/rocm), after which torch -- imported later -- is
+    bound to a runtime it was not built with and finds no GPU.  So whichever of the two comes first, the
+    runtime that gets mapped is torch's: map it here (by path, without importing torch) before libazhip."""
+    import sys
+    if "torch" in sys.modules or hip_runtimes_mapped():
+        return                                          # a runtime is already in: the loader reuses it by soname
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return                                          # no torch here: the system runtime is the only one
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libazhip.so; fails loudly if the HIP extension has not been built."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise AzError("libazhip.so not built (run `make -C alphazero_amd/csrc`); there is no CPU fallback")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
+        rts = hip_runtimes_mapped()
+        if len(rts) > 1:
+            raise AzError("two HIP runtimes are mapped into this process (%s): device pointers, streams and RCCL "
+                          "would not be shared between them; import alphazero_amd.capi or torch before any other "
+                          "library that links libamdhip64" % ", ".join(rts))
         L.az_last_error.restype = C.c_char_p
         L.az_weights_size.restype = C.c_size_t
         L.az_stream.restype = C.c_void_p
