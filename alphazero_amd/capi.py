@@ -22,6 +22,7 @@ EXPORTS = [
     "az_last_error", "az_ctx_create", "az_ctx_destroy", "az_sync", "az_stream", "az_weights_size",
     "az_load_weights", "az_load_weights_dev", "az_env_reset", "az_env_step", "az_env_boards",
     "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
+    "az_tower_forward_static", "az_tower_static_max_batch",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
@@ -106,6 +107,9 @@ def load():
         L.az_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.az_load_weights_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.az_tower_forward_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.az_tower_forward_static.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.az_tower_static_max_batch.restype = C.c_size_t
+        L.az_tower_static_max_batch.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -174,6 +178,13 @@ class Engine:
 
     def tower_forward_dev(self, boards_ptr, B, policy_ptr, value_ptr):
         _chk(load().az_tower_forward_dev(self.h, C.c_void_p(boards_ptr), B, C.c_void_p(policy_ptr), C.c_void_p(value_ptr)))
+
+    def tower_forward_static(self, boards_ptr, B, policy_ptr, value_ptr):
+        """az_tower_forward_dev without any allocation: activations in the library's per-GPU static array."""
+        _chk(load().az_tower_forward_static(self.h, C.c_void_p(boards_ptr), B, C.c_void_p(policy_ptr), C.c_void_p(value_ptr)))
+
+    def tower_static_max_batch(self):
+        return int(load().az_tower_static_max_batch(self.h))
 
     # -- Env ---------------------------------------------------------------
     def env_reset(self):

@@ -14,8 +14,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
+
+// Activation images of az_tower_forward_static: one array per GPU, alive until the process ends.  In host
+// code the array's name is only a handle for hipGetSymbolAddress; every use of the memory goes through
+// the per-device address kept in g_scratch_ptr.
+#define AZ_STATIC_SCRATCH_BYTES (64u << 20)
+#define AZ_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[AZ_STATIC_SCRATCH_BYTES];
+static unsigned char* g_scratch_ptr[AZ_MAX_DEVICES];
+static std::mutex g_scratch_mu;
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -129,6 +139,14 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
     if (ndev < 1) return fail(AZ_E_HIP, "no HIP device: libazhip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(AZ_E_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
     HIPCHK(hipSetDevice(cfg->device));
+    if (cfg->device < AZ_MAX_DEVICES) {                      // once per device, with that device current
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[cfg->device]) {
+            void* p = nullptr;
+            HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[cfg->device] = (unsigned char*)p;
+        }
+    }
     az_ctx* c = new az_ctx;
     c->cfg = *cfg;
     const int rc = ctx_build(c, cfg);
@@ -356,6 +374,45 @@ extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* 
     HIPCHK(hipMemcpyAsync(value, c->tower_val, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
+}
+
+// az_tower_forward_dev for callers that cannot allocate: on a per-layer context the two activation images
+// live in this GPU's `scratch` array instead of the context's own buffers, so the batch is bounded by the
+// array, not by az_config.G.  No hipMalloc / hipFree, no host allocation, no event.  Every call on a GPU
+// shares that GPU's array: calls that overlap on one GPU race.  The array keeps the last call's contents, so
+// the rows that must read as zero (the guard rows at both ends and the rows behind the last board) are
+// cleared on every call.
+extern "C" size_t az_tower_static_max_batch(const az_ctx* c) {
+    if (!c || c->cfg.eval_mode != AZ_EVAL_TOWER) return 0;
+    if (c->fused) return (size_t)c->Bmax;                    // the fused kernel has no scratch: the context's own limit
+    const size_t row = (size_t)c->C_pad * 2, fixed = 2 * (size_t)c->Gd + 255;   // guard rows + round-up to a 256-row tile
+    const size_t rows = AZ_STATIC_SCRATCH_BYTES / 2 / row;
+    return rows > fixed ? (rows - fixed) / (size_t)c->P : 0;
+}
+
+extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
+    NEED(c); NEED(boards_dev); NEED(policy_dev); NEED(value_dev);
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (c->fused) {                                          // activations stay in LDS: nothing to place
+        if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
+        return tower_launch(c, boards_dev, B, policy_dev, value_dev, nullptr, nullptr, false);
+    }
+    unsigned char* const base = c->cfg.device < AZ_MAX_DEVICES ? g_scratch_ptr[c->cfg.device] : nullptr;
+    if (!base) return fail(AZ_E_STATE, "static scratch of device %d was not set up", c->cfg.device);
+    const size_t maxB = az_tower_static_max_batch(c);
+    if (B < 1 || (size_t)B > maxB)
+        return fail(AZ_E_CAPACITY, "batch %d does not fit the static scratch: at most %zu boards of %dx%d with %d channels (%u MiB per GPU)",
+                    B, maxB, c->cfg.N, c->cfg.N, c->C_pad, AZ_STATIC_SCRATCH_BYTES >> 20);
+    const size_t row = (size_t)c->C_pad * 2;
+    const size_t M = (size_t)B * c->P, M_pad = (M + 255) / 256 * 256, rows = M_pad + 2 * (size_t)c->Gd;
+    unsigned char* const img[2] = {base, base + AZ_STATIC_SCRATCH_BYTES / 2};
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipMemsetAsync(img[k], 0, (size_t)c->Gd * row, c->stream));
+        HIPCHK(hipMemsetAsync(img[k] + ((size_t)c->Gd + M) * row, 0, (rows - c->Gd - M) * row, c->stream));
+    }
+    return tower_launch(c, boards_dev, B, policy_dev, value_dev, (unsigned short*)img[0], (unsigned short*)img[1], false);
 }
 
 // --------------------------------------------------------------------- env

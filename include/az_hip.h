@@ -133,6 +133,16 @@ int az_env_load(az_ctx*, const int32_t* hist, const int32_t* hist_len);
 int az_tower_forward(az_ctx*, const uint8_t* boards, int B, float* policy, float* value);
 int az_tower_forward_dev(az_ctx*, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev);
 
+/* No counterpart in the reference.  az_tower_forward_dev for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): on a context
+ * whose tower runs one launch per convolution the activation images live in a 64 MiB array that the
+ * library holds once per GPU (file scope, until the process ends) instead of in buffers sized by
+ * az_config.G, and the call makes no allocation of any kind.  B is bounded by that array
+ * (az_tower_static_max_batch; larger batches return AZ_E_CAPACITY), not by az_config.G.  Every call on a
+ * GPU shares the GPU's array: two such calls that overlap in time on one GPU race. */
+int az_tower_forward_static(az_ctx*, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev);
+size_t az_tower_static_max_batch(const az_ctx*);
+
 /* util.h:42-58 made an input: noise f32 [G,N*N], used in legal-action order
  * for every freshly created root (mcts.hpp:432-446). */
 int az_set_noise(az_ctx*, const float* noise);
