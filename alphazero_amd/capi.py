@@ -23,6 +23,9 @@ EXPORTS = [
     "az_load_weights", "az_load_weights_dev", "az_env_reset", "az_env_step", "az_env_boards",
     "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
     "az_tower_forward_static", "az_tower_static_max_batch",
+    "az_group_create", "az_group_destroy", "az_group_contexts", "az_group_context", "az_group_load_weights",
+    "az_group_selfplay_begin", "az_group_selfplay_run", "az_group_sync", "az_group_replay_drain", "az_group_get_stats",
+    "az_ctx_cells", "az_merge_drain", "az_device_count", "az_get_noise",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
@@ -226,6 +229,11 @@ class Engine:
         noise = np.ascontiguousarray(noise, np.float32)
         assert noise.size == self.G * self.A
         _chk(load().az_set_noise(self.h, _ptr(noise)))
+
+    def get_noise(self):
+        out = np.empty((self.G, self.A), np.float32)
+        _chk(load().az_get_noise(self.h, _ptr(out)))
+        return out
 
     def search(self, budget):
         out = np.empty((self.G, self.A), np.float32)

@@ -40,6 +40,8 @@ static int fail(int code, const char* fmt, ...) {
 #define NEED(ptr) do { if (!(ptr)) return fail(AZ_E_ARG, "null argument: %s", #ptr); } while (0)
 
 extern "C" const char* az_last_error(void) { return g_err.c_str(); }
+// for the library's other translation units (group.hip): record an error for az_last_error
+extern "C" int az_internal_fail(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
 
 struct az_ctx {
     az_config cfg;
@@ -50,7 +52,8 @@ struct az_ctx {
     int Bmax = 0;
     // tower
     bool have_weights = false;
-    unsigned short *actX = nullptr, *actH = nullptr;      // [rows][C_pad] bf16
+    unsigned short *actX = nullptr, *actH = nullptr;      // per-layer path: [rows][C_pad] 16-bit inputs of the convolutions
+    float* actR = nullptr;                                // per-layer path: [rows][C_pad] fp32 residual stream
     size_t act_rows = 0;
     float *stem_w = nullptr, *stem_b = nullptr;           // [C_pad][27], [C_pad]
     unsigned short* stem_wbf = nullptr;                   // [128][32] bf16, fused path
@@ -229,6 +232,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
             c->act_rows = M_pad + 2 * (size_t)c->Gd;
             AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
+            AZCHK(dalloc(c, &c->actR, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27));
             AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
             AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
@@ -253,7 +257,13 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     return AZ_OK;
 }
 
+extern "C" int az_device_count(void) {
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    return n;
+}
 extern "C" int az_tower_is_fused(const az_ctx* c) { return c && c->fused ? 1 : 0; }
+extern "C" int az_ctx_cells(const az_ctx* c) { return c ? c->A : 0; }
 extern "C" int az_selfplay_batch(const az_ctx* c) { return c ? c->cfg.G * c->d.L : 0; }
 extern "C" int az_sync(az_ctx* c) { NEED(c); return sync_all(c); }
 extern "C" void* az_stream(az_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -319,10 +329,12 @@ extern "C" int az_load_weights_dev(az_ctx* c, const float* blob_dev, size_t n_fl
 }
 
 // ------------------------------------------------------------------- tower
-// actX / actH: the two activation images of the per-layer path ([guard + M_pad + guard][C_pad] 16-bit rows,
-// guard and padding rows zero); unused by the fused kernel, whose activations never leave LDS.
+// actX / actH / actR: the activation images of the per-layer path ([guard + M_pad + guard][C_pad] rows, guard
+// and padding rows zero): 16-bit inputs of a block's two convolutions and the fp32 residual stream, which every
+// block's second convolution updates in place and the heads read; unused by the fused kernel, whose
+// activations never leave LDS and registers.
 static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev,
-                        unsigned short* actX, unsigned short* actH, bool sampled) {
+                        unsigned short* actX, unsigned short* actH, float* actR, bool sampled) {
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled, c->stream);
@@ -332,7 +344,7 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
-    az_launch_stem(c->stream, c->prec, planes_dev, actX, c->stem_w, c->stem_b, B, N, Cp, Gd);
+    az_launch_stem(c->stream, c->prec, planes_dev, actX, actR, c->stem_w, c->stem_b, B, N, Cp, Gd);
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
@@ -340,10 +352,10 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         az_launch_conv3x3(c->stream, c->prec, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
         on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, actH, actX, actX, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
     }
-    az_launch_heads(c->stream, c->prec, actX, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }
@@ -352,7 +364,7 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
     if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
-    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, sampled);
+    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, c->actR, sampled);
 }
 
 extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
@@ -385,8 +397,9 @@ extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* 
 extern "C" size_t az_tower_static_max_batch(const az_ctx* c) {
     if (!c || c->cfg.eval_mode != AZ_EVAL_TOWER) return 0;
     if (c->fused) return (size_t)c->Bmax;                    // the fused kernel has no scratch: the context's own limit
+    // the array holds three images of the same rows: two 16-bit ones (a quarter each) and the fp32 one (a half)
     const size_t row = (size_t)c->C_pad * 2, fixed = 2 * (size_t)c->Gd + 255;   // guard rows + round-up to a 256-row tile
-    const size_t rows = AZ_STATIC_SCRATCH_BYTES / 2 / row;
+    const size_t rows = AZ_STATIC_SCRATCH_BYTES / 4 / row;
     return rows > fixed ? (rows - fixed) / (size_t)c->P : 0;
 }
 
@@ -397,7 +410,7 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
     HIPCHK(hipSetDevice(c->cfg.device));
     if (c->fused) {                                          // activations stay in LDS: nothing to place
         if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
-        return tower_launch(c, boards_dev, B, policy_dev, value_dev, nullptr, nullptr, false);
+        return tower_launch(c, boards_dev, B, policy_dev, value_dev, nullptr, nullptr, nullptr, false);
     }
     unsigned char* const base = c->cfg.device < AZ_MAX_DEVICES ? g_scratch_ptr[c->cfg.device] : nullptr;
     if (!base) return fail(AZ_E_STATE, "static scratch of device %d was not set up", c->cfg.device);
@@ -407,12 +420,13 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
                     B, maxB, c->cfg.N, c->cfg.N, c->C_pad, AZ_STATIC_SCRATCH_BYTES >> 20);
     const size_t row = (size_t)c->C_pad * 2;
     const size_t M = (size_t)B * c->P, M_pad = (M + 255) / 256 * 256, rows = M_pad + 2 * (size_t)c->Gd;
-    unsigned char* const img[2] = {base, base + AZ_STATIC_SCRATCH_BYTES / 2};
-    for (int k = 0; k < 2; ++k) {
-        HIPCHK(hipMemsetAsync(img[k], 0, (size_t)c->Gd * row, c->stream));
-        HIPCHK(hipMemsetAsync(img[k] + ((size_t)c->Gd + M) * row, 0, (rows - c->Gd - M) * row, c->stream));
+    unsigned char* const img[3] = {base, base + AZ_STATIC_SCRATCH_BYTES / 4, base + AZ_STATIC_SCRATCH_BYTES / 2};
+    for (int k = 0; k < 3; ++k) {
+        const size_t rb = k == 2 ? 2 * row : row;            // bytes per row: 16-bit images, fp32 residual stream
+        HIPCHK(hipMemsetAsync(img[k], 0, (size_t)c->Gd * rb, c->stream));
+        HIPCHK(hipMemsetAsync(img[k] + ((size_t)c->Gd + M) * rb, 0, (rows - c->Gd - M) * rb, c->stream));
     }
-    return tower_launch(c, boards_dev, B, policy_dev, value_dev, (unsigned short*)img[0], (unsigned short*)img[1], false);
+    return tower_launch(c, boards_dev, B, policy_dev, value_dev, (unsigned short*)img[0], (unsigned short*)img[1], (float*)img[2], false);
 }
 
 // --------------------------------------------------------------------- env
@@ -521,6 +535,14 @@ extern "C" int az_set_noise(az_ctx* c, const float* noise) {
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(c->d.noise, noise, (size_t)c->cfg.G * c->A * 4, hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
+extern "C" int az_get_noise(az_ctx* c, float* noise) {
+    NEED(c); NEED(noise);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpyAsync(noise, c->d.noise, (size_t)c->cfg.G * c->A * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
 }
 

@@ -8,14 +8,14 @@ extern "C" {
 int  az_tower_configure(void);
 size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows);   // dynamic LDS of az_tower_fused_kernel
 
-void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, const float* w,
+void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
                     const float* bias, int B, int N, int C_pad, int Gd);
 void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
-                       const unsigned short* resid, const unsigned short* wpk, const float* bias,
+                       float* resid, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu);
 void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                            const float* stem_b, const unsigned short* wpk, const float* bias,
                            const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers);
-void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,
+void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
                      float* value, int B, int N, int C_pad, int Gd);
 }

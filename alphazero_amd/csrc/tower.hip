@@ -91,7 +91,7 @@ template <> struct Prec<1> {
 // One block per board.  w: [C_pad][27] fp32 (BN folded), bias [C_pad].
 template <int PR>
 __global__ void __launch_bounds__(256)
-az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out,
+az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out, float* __restrict__ out32,
                const float* __restrict__ w, const float* __restrict__ bias,
                int N, int C_pad, int Gd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -127,6 +127,7 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
         }
         const unsigned pk = (unsigned)Prec<PR>::to16(a0) | ((unsigned)Prec<PR>::to16(a1) << 16);
         *(unsigned*)(out + ((size_t)(Gd + b * P + p)) * C_pad + c) = pk;
+        *(float2*)(out32 + ((size_t)(Gd + b * P + p)) * C_pad + c) = make_float2(a0, a1);     // the residual stream stays fp32
     }
 }
 
@@ -163,7 +164,7 @@ __device__ __forceinline__ float relu_cap(float x, float cap) { return __builtin
 template <int PR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // LDS allows two workgroups: 256 registers each
 az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
-                       const unsigned short* __restrict__ resid, const unsigned short* __restrict__ wpk,
+                       float* resid /* fp32 residual stream, updated in place; null: none */, const unsigned short* __restrict__ wpk,
                        const float* __restrict__ bias, int C_pad, int M, int N, int Gd, int relu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = N + 1, P = W * W;
@@ -269,22 +270,9 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
 #undef STAGE_A2
     __syncthreads();                                         // all waves done with sA: reuse rows 0..127 for the epilogue
 
-    // epilogue through LDS (this column block's 128 channels of the tile's 128 rows):
-    // coalesced residual load -> + bias (+ residual), ReLU, zero padding rows -> coalesced store
-    if (resid) {
-        uint4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = tid + 256 * u, r = i >> 4, c = i & 15;
-            v[u] = *(const uint4*)(resid + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = tid + 256 * u, r = i >> 4, c = i & 15;
-            *(uint4*)(sA + r * A_STRIDE + c * 16) = v[u];
-        }
-        __syncthreads();
-    }
+    // epilogue (this column block's 128 channels of the tile's 128 rows): + bias (+ the fp32 residual stream, read
+    // and rewritten in place straight from the accumulator layout: this kernel is the cross-check, not the fast
+    // path), ReLU, zero padding rows -> 16-bit rows through LDS -> coalesced store
     {
         const int rr = 32 * wv + l31;
         const int m = m0 + rr;
@@ -293,6 +281,7 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
         const unsigned keep = real ? 0xFFFFFFFFu : 0u;
         const float cap = real ? Prec<PR>::cap() : 0.f;
         unsigned char* rowp = sA + rr * A_STRIDE + 8 * h;
+        float* const rrow = resid ? resid + (size_t)(Gd + m) * C_pad + nb * 128 + 4 * h : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -302,18 +291,20 @@ az_conv3x3_t128_kernel(const unsigned short* __restrict__ in, unsigned short* __
                 float v0 = acc[i][4 * q + 0] + bv.x, v1 = acc[i][4 * q + 1] + bv.y;
                 float v2 = acc[i][4 * q + 2] + bv.z, v3 = acc[i][4 * q + 3] + bv.w;
                 if (resid) {
-                    const uint2 rv = *(const uint2*)(rowp + cch * 2);
-                    v0 += Prec<PR>::from16((unsigned short)(rv.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(rv.x >> 16));
-                    v2 += Prec<PR>::from16((unsigned short)(rv.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(rv.y >> 16));
+                    const float4 rv = *(const float4*)(rrow + cch);
+                    v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
                 }
                 uint2 o;
                 if (relu) {                                  // ReLU + saturation + padding mask: one v_med3 per value
-                    o.x = Prec<PR>::pack2(relu_cap(v0, cap), relu_cap(v1, cap));
-                    o.y = Prec<PR>::pack2(relu_cap(v2, cap), relu_cap(v3, cap));
+                    v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap);
+                    o.x = Prec<PR>::pack2(v0, v1);
+                    o.y = Prec<PR>::pack2(v2, v3);
                 } else {
+                    if (!real) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
                     o.x = ((unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16)) & keep;
                     o.y = ((unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16)) & keep;
                 }
+                if (resid) *(float4*)(rrow + cch) = make_float4(v0, v1, v2, v3);
                 *(uint2*)(rowp + cch * 2) = o;
             }
     }
@@ -342,8 +333,8 @@ static inline __host__ __device__ int t4_slab_rows(int Gd) { return (T4_M + 2 * 
 
 template <int PR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* out,
-                       const unsigned short* resid /* may alias out */, const unsigned short* __restrict__ wpk,
+az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                       float* resid /* fp32 residual stream, updated in place; null: none */, const unsigned short* __restrict__ wpk,
                        const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Prec<PR>::vec vec;
@@ -470,22 +461,83 @@ az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* ou
 #undef CHUNK_SRC4
     __syncthreads();                                         // all waves done with the buffers: LDS becomes the output image
 
-    // epilogue: 256 rows x 128 channels, 256-byte rows, piece c of row r at c ^ (r & 15)
-    unsigned char* const sO = smem;
     if (resid) {
-        // DMA q covers image rows 4q .. 4q+3 (lane: row 4q + (lane >> 4), physical piece lane & 15 holds logical
-        // piece (lane & 15) ^ (row & 15) = ((lane & 15) ^ (lane >> 4)) ^ (4q & 15)); wave w issues q = w, w+4, ...
-        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(resid + (size_t)(Gd + m0) * C_pad + nb * 128), 0, T4_M * C_pad * 2, 0x00020000);
-        const unsigned lane_piece = (unsigned)((lane & 15) ^ (lane >> 4));
-        const unsigned row_off = (unsigned)((lane >> 4) * C_pad * 2);
+        // Second convolution of a ResBlock: x = relu(conv + bias + residual) with the residual stream in fp32
+        // (network.hpp:36 in the reference's own precision; only the copy that feeds the next convolution is
+        // rounded to 16 bits).  Two passes of 128 tile rows; a wave handles its own 32 rows per pass end to end
+        // (rows 64 wv + 32 p + [0, 32) of the tile = rows 32 wv + [0, 32) of the LDS image), so the passes need
+        // no hand-over between waves.  Image: fp32 [128 rows][128 ch], 512-byte rows, 16-byte piece c of row r
+        // at c ^ (r & 31); in by LDS DMA, arithmetic in place, fp32 rows and their 16-bit copies out whole.
+        unsigned char* const img = smem + (size_t)wvu * 32 * 512;            // this wave's 32 image rows
+        const size_t rpitch = (size_t)C_pad * 4;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int trow0 = 64 * wv + 32 * p;                              // first tile row of this wave's pass
+            float* const gbase = resid + (size_t)(Gd + m0 + trow0) * C_pad + nb * 128;
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (int)(32 * rpitch), 0x00020000);
 #pragma unroll 4
-        for (int q = wvu; q < T4_M / 4; q += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(sO + q * 1024), 16,
-                                                     row_off + ((lane_piece ^ (unsigned)((4 * q) & 15)) << 4), q * 4 * C_pad * 2, 0, 0);
-        AZ_DMA_LANDED();
-        __syncthreads();
+            for (int q = 0; q < 16; ++q) {                                   // DMA q: image rows 2q, 2q + 1
+                const int r = 2 * q + (lane >> 5);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(img + q * 1024), 16,
+                                                         (unsigned)(r * rpitch) + (unsigned)(((lane & 31) ^ r) << 4), 0, 0, 0);
+            }
+            AZ_DMA_LANDED();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int m = m0 + trow0 + l31;
+                const int pp = m % P;
+                const bool real = m < M && (pp / W) < N && (pp % W) < N;
+                const float cap = real ? Prec<PR>::cap() : 0.f;
+                unsigned char* const rowp = img + l31 * 512;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bv = *(const float4*)(bias + nb * 128 + 32 * i + 8 * q + 4 * h);
+                        float4* const slot = (float4*)(rowp + (((8 * i + 2 * q + h) ^ l31) << 4));   // channels 32 i + 8 q + 4 h .. +3
+                        const float4 rv = *slot;
+                        float v0 = acc[i][p][4 * q + 0] + bv.x, v1 = acc[i][p][4 * q + 1] + bv.y;
+                        float v2 = acc[i][p][4 * q + 2] + bv.z, v3 = acc[i][p][4 * q + 3] + bv.w;
+                        v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+                        if (relu) { v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap); }
+                        else if (!real) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+                        *slot = make_float4(v0, v1, v2, v3);
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // this wave's LDS writes are done (lgkmcnt 0)
+            __builtin_amdgcn_sched_barrier(0);
+            // fp32 rows back to the residual stream: 2 rows per trip
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int r = 2 * it + (lane >> 5), ph = lane & 31;
+                const float4 v = *(const float4*)(img + r * 512 + (ph << 4));
+                *(float4*)(gbase + (size_t)r * C_pad + ((ph ^ r) << 2)) = v;
+            }
+            // and their 16-bit copies, the next convolution's input: 4 rows per trip, 8 channels per lane
+            unsigned short* const obase = out + (size_t)(Gd + m0 + trow0) * C_pad + nb * 128;
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int r = 4 * it + (lane >> 4), c = lane & 15;
+                const float4 a = *(const float4*)(img + r * 512 + (((2 * c) ^ r) << 4));
+                const float4 bq = *(const float4*)(img + r * 512 + (((2 * c + 1) ^ r) << 4));
+                uint4 o;
+                if (relu) {                                                  // already in [0, cap]
+                    o.x = Prec<PR>::pack2(a.x, a.y); o.y = Prec<PR>::pack2(a.z, a.w);
+                    o.z = Prec<PR>::pack2(bq.x, bq.y); o.w = Prec<PR>::pack2(bq.z, bq.w);
+                } else {
+                    o.x = (unsigned)Prec<PR>::to16(a.x) | ((unsigned)Prec<PR>::to16(a.y) << 16);
+                    o.y = (unsigned)Prec<PR>::to16(a.z) | ((unsigned)Prec<PR>::to16(a.w) << 16);
+                    o.z = (unsigned)Prec<PR>::to16(bq.x) | ((unsigned)Prec<PR>::to16(bq.y) << 16);
+                    o.w = (unsigned)Prec<PR>::to16(bq.z) | ((unsigned)Prec<PR>::to16(bq.w) << 16);
+                }
+                *(uint4*)(obase + (size_t)r * C_pad + c * 8) = o;
+            }
+            __syncthreads();                                                 // reads of this pass are done before the next pass's DMA lands
+        }
+        return;
     }
+    // first convolution of a ResBlock: 256 rows x 128 channels of 16-bit output, 256-byte rows, piece c of row r at c ^ (r & 15)
+    unsigned char* const sO = smem;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rr = 64 * wv + 32 * j + l31;
@@ -501,14 +553,9 @@ az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* ou
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *(const float4*)(bias + nb * 128 + 32 * i + 8 * q + 4 * h);
-                float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
-                float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
+                const float v0 = acc[i][j][4 * q + 0] + bv.x, v1 = acc[i][j][4 * q + 1] + bv.y;
+                const float v2 = acc[i][j][4 * q + 2] + bv.z, v3 = acc[i][j][4 * q + 3] + bv.w;
                 uint2* const slot = (uint2*)(rowp + (((4 * i + q) ^ sw) << 4));   // channels 32 i + 8 q + 4 h .. +3
-                if (resid) {
-                    const uint2 r2 = *slot;
-                    v0 += Prec<PR>::from16((unsigned short)(r2.x & 0xFFFFu)); v1 += Prec<PR>::from16((unsigned short)(r2.x >> 16));
-                    v2 += Prec<PR>::from16((unsigned short)(r2.y & 0xFFFFu)); v3 += Prec<PR>::from16((unsigned short)(r2.y >> 16));
-                }
                 uint2 o;
                 if (relu) {                                  // ReLU + saturation + padding mask: one v_med3 per value
                     o.x = Prec<PR>::pack2(relu_cap(v0, cap), relu_cap(v1, cap));
@@ -1029,7 +1076,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 // fc1w [64][A], fc1b [64], fc2w [2][64], fc2b [2].
 template <int PR>
 __global__ void __launch_bounds__(256)
-az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ hp,
+az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const float* __restrict__ hp,
                 float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int A = N * N, W = N + 1, P = W * W;
@@ -1048,17 +1095,12 @@ az_heads_kernel(const unsigned short* __restrict__ x, const float* __restrict__ 
 
     for (int a = tid; a < A; a += 256) {
         const int y = a / N, xx = a % N;
-        const unsigned short* row = x + ((size_t)(Gd + b * P + y * W + xx)) * C_pad;
+        const float* row = x + ((size_t)(Gd + b * P + y * W + xx)) * C_pad;
         float sp = 0.f, sv = 0.f;
-        for (int c = 0; c < C_pad; c += 8) {
-            const uint4 v = *(const uint4*)(row + c);
-            const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float lo = Prec<PR>::from16((unsigned short)(u[t] & 0xFFFFu)), hi = Prec<PR>::from16((unsigned short)(u[t] >> 16));
-                sp += lo * wp[c + 2 * t] + hi * wp[c + 2 * t + 1];
-                sv += lo * wvv[c + 2 * t] + hi * wvv[c + 2 * t + 1];
-            }
+        for (int c = 0; c < C_pad; c += 4) {
+            const float4 v = *(const float4*)(row + c);
+            sp += v.x * wp[c] + v.y * wp[c + 1] + v.z * wp[c + 2] + v.w * wp[c + 3];
+            sv += v.x * wvv[c] + v.y * wvv[c + 1] + v.z * wvv[c + 2] + v.w * wvv[c + 3];
         }
         s_logit[a] = sp + bp;
         s_u[a] = fmaxf(sv + bvv, 0.f);
@@ -1126,14 +1168,14 @@ extern "C" int az_tower_configure(void) {
 // prec: 0 = bf16 operands, 1 = fp16 operands
 #define BY_PREC(kern, ...) do { if (prec == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
 
-extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, const float* w,
+extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
                                const float* bias, int B, int N, int C_pad, int Gd) {
     const size_t sm = (size_t)C_pad * 28 * 4 + 3 * N * N + 16;
-    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, w, bias, N, C_pad, Gd);
+    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, w, bias, N, C_pad, Gd);
 }
 
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
-                                  const unsigned short* resid, const unsigned short* wpk, const float* bias,
+                                  float* resid, const unsigned short* wpk, const float* bias,
                                   int C_pad, int M, int N, int Gd, int relu) {
     if (!getenv("AZ_CONV_T128")) {                                        // 256 rows x 128 channels, two workgroups per CU
         const int tiles = (M + T4_M - 1) / T4_M;
@@ -1176,7 +1218,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     }
 }
 
-extern "C" void az_launch_heads(hipStream_t s, int prec, const unsigned short* x, const float* hp, float* policy,
+extern "C" void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
                                 float* value, int B, int N, int C_pad, int Gd) {
     const size_t sm = (size_t)(2 * N * N + 256 + 64) * 4;
     BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd);

@@ -3,8 +3,10 @@
 // (generate.cpp:37-123): same argv, same ckpt_location.txt weight hand-off,
 // same PUSH stream on tcp://*:5555 in the trainer's 3-frame format, "press
 // enter" to stop (generate.cpp:19-23).  Instead of one game searched by
-// nthreads CPU threads it advances AZ_GAMES (default 512) games in lockstep on
-// the GPU; <nthreads> is accepted and ignored.
+// nthreads CPU threads it advances AZ_GAMES (default 512) games per GPU in lockstep
+// on every GPU named by AZ_GPUS ("all", a count, or a list; default: AZ_DEVICE or 0),
+// one host thread per GPU; new weights reach the GPUs by one RCCL broadcast; all rows
+// leave through the one PUSH socket.  <nthreads> is accepted and ignored.
 #include <atomic>
 #include <chrono>
 #include <iostream>
@@ -35,7 +37,9 @@ int main(int argc, char const* argv[]) {
     const char* max_s = getenv("AZ_SECONDS");
     const int games = g ? atoi(g) : 512;
 
-    az::SelfPlay<Env> agent(games, iter_budget, 3, 3, dev ? atoi(dev) : 0, std::random_device{}());
+    const std::vector<int> devices = az::parse_gpus(getenv("AZ_GPUS"), dev ? atoi(dev) : 0, az_device_count());
+    az::SelfPlay<Env> agent(games, iter_budget, 3, 3, devices[0], std::random_device{}(), 0, 0, devices);
+    std::cout << "GPUs: " << devices.size() << " | games per GPU: " << games << std::endl;
     az::ReplayBuffer<Env> buffer(GEN, "*", port ? port : "5555");
     agent.load();
     agent.begin();

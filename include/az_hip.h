@@ -97,6 +97,8 @@ typedef struct az_stats {
 } az_stats;
 
 const char* az_last_error(void);
+/* torch::cuda::is_available / device choice of the Evaluator (evaluator.hpp:141-144): GPUs this process sees */
+int az_device_count(void);
 
 /* MCTS<Env>::MCTS + Evaluator<Env>::Evaluator (mcts.hpp:41-73, evaluator.hpp:48-77):
  * allocates all device state for G games and the tower. */
@@ -146,6 +148,9 @@ size_t az_tower_static_max_batch(const az_ctx*);
 /* util.h:42-58 made an input: noise f32 [G,N*N], used in legal-action order
  * for every freshly created root (mcts.hpp:432-446). */
 int az_set_noise(az_ctx*, const float* noise);
+/* The noise each game's latest fresh root was mixed with, f32 [G,N*N], entry k = k-th legal action; with
+ * AZ_NOISE_DEVICE that is the device's own dirichlet(n_actions, 0.05) draw (util.h:42-58). */
+int az_get_noise(az_ctx*, float* noise);
 
 /* MCTS::search_probs (mcts.hpp:105-155) for all G games from their current
  * env states, including root reuse (mcts.hpp:385-421): out f32 [G,N*N]. */
@@ -179,6 +184,35 @@ int az_selfplay_run(az_ctx*, int rounds);
  * Returns the number of rows copied (<= cap) or a negative error. */
 int az_replay_drain(az_ctx*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
 int az_get_stats(az_ctx*, az_stats*);
+
+/* generate.cpp:37-123 as ONE process over every GPU of the node (the reference runs one generator process;
+ * its MCTS/Evaluator pair, mcts.hpp:41-73, becomes one context per GPU): games are sharded by GPU, trees
+ * never interact, so nothing in the data path is a collective.  cfg describes ONE context (cfg->G games
+ * each; cfg->device is ignored, game_slot_base numbers the group's games from cfg->game_slot_base); the
+ * group holds contexts_per_device contexts on each of the n_devices GPUs, one host thread per GPU issues that
+ * GPU's launches.  az_group_load_weights is load_network (util.h:60-105) for the node: the blob goes to the
+ * first GPU once, RCCL broadcasts it over xGMI (ncclBroadcast on a communicator of the group's GPUs, bound
+ * from librccl.so.1 at run time), every GPU folds and packs its copy on the device.  az_group_replay_drain is
+ * the gather of finished rows to the process that owns the PUSH socket (replay.hpp:41-54): rows of every
+ * context in context order (GPU-major), same layout as az_replay_drain.  Counters of az_group_get_stats are
+ * sums over the contexts (rounds, max_nodes, max_edges: maxima). */
+typedef struct az_group az_group;
+int az_group_create(az_group** out, const az_config* cfg, const int* devices, int n_devices, int contexts_per_device);
+int az_group_destroy(az_group*);
+int az_group_contexts(const az_group*);
+az_ctx* az_group_context(az_group*, int i);
+int az_group_load_weights(az_group*, const float* blob, size_t n_floats);
+int az_group_selfplay_begin(az_group*, int iter_budget);
+int az_group_selfplay_run(az_group*, int rounds);
+int az_group_sync(az_group*);
+int az_group_replay_drain(az_group*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
+int az_group_get_stats(az_group*, az_stats*);
+/* The host-side merge az_group_replay_drain is made of, usable on its own (and without a GPU): sources are
+ * drained in order through fn(src, cap_left, row buffers at the next free row) until cap rows are out. */
+typedef int (*az_drain_fn)(void* src, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
+int az_merge_drain(int n_src, az_drain_fn fn, void* const* srcs, int A, int cap,
+                   uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
+int az_ctx_cells(const az_ctx*);                  /* N*N of the context's board */
 
 /* Env::step on the host (the rules the C++ Env shim and az_env_load use; same
  * rules as the device kernels): returns 1 done, 0 running, AZ_E_ARG illegal. */

@@ -40,6 +40,9 @@ TOWER_CASES = [
     ("n15_cfg2", 15, synth.NETCONFIG2, 4, 5, 1.0, 1.0),
     ("n15_cfg2_sharp", 15, synth.NETCONFIG2, 4, 6, 20.0, 20.0),
     ("n3_cfg2", 3, synth.NETCONFIG2, 4, 7, 5.0, 5.0),
+    # BASELINE configs[4]: 20 ResBlocks x 256 channels (41 convolutions deep), random-init and sharpened heads
+    ("n15_c256x21", 15, [256] * 21, 8, 8, 1.0, 1.0),
+    ("n15_c256x21_sharp", 15, [256] * 21, 8, 9, 20.0, 20.0),
 ]
 
 
@@ -72,7 +75,10 @@ def gen_tower(name, N, Cs, B, wseed, pg, fg):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]                                  # fixture names to (re)generate; none = all
     for c in TOWER_CASES:
-        gen_tower(*c)
+        if not only or c[0] in only:
+            gen_tower(*c)
     for c in MCTS_CASES:
-        gen_mcts(*c)
+        if not only or c[0] in only:
+            gen_mcts(*c)

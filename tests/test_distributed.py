@@ -79,3 +79,54 @@ def test_broadcast_and_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: "ok", 1: "ok"}, res
+
+
+def test_merge_drain_orders_rows_by_source_with_two_fake_ranks():
+    """az_merge_drain (the host-side merge az_group_replay_drain is made of) with two fake GPU ranks as
+    callbacks: rows come out source-major and in each source's own order, a cap smaller than the total
+    leaves the rest in its source for the next call, a source's error ends the merge."""
+    import ctypes as C
+    from alphazero_amd import capi
+    L = capi.load()
+    A = 9
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                     C.POINTER(C.c_float), C.POINTER(C.c_float))
+    L.az_merge_drain.argtypes = [C.c_int, FN, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    # fake rank r holds rows tagged (r, i): cells all r + 1, to_move i % 2, policy i / 100, reward (r, -r)
+    pending = {0: list(range(5)), 1: list(range(7))}
+    calls = []
+
+    def drain(src, cap, cells, tm, pol, rew):
+        r = int(src or 0) - 1
+        if r == 2:
+            return -4
+        calls.append((r, cap))
+        n = min(cap, len(pending[r]))
+        for k in range(n):
+            i = pending[r].pop(0)
+            for a in range(A):
+                cells[k * A + a] = r + 1
+                pol[k * A + a] = i / 100.0
+            tm[k] = i % 2
+            rew[2 * k], rew[2 * k + 1] = float(r), float(-r)
+        return n
+    fn = FN(drain)
+    srcs = (C.c_void_p * 2)(1, 2)                              # opaque handles: rank + 1
+
+    def merge(cap, srcs=srcs, n=2):
+        cells = np.zeros((cap, A), np.uint8); tm = np.zeros(cap, np.uint8)
+        pol = np.zeros((cap, A), np.float32); rew = np.zeros((cap, 2), np.float32)
+        k = L.az_merge_drain(n, fn, srcs, A, cap, cells.ctypes.data, tm.ctypes.data, pol.ctypes.data, rew.ctypes.data)
+        return k, cells[:max(k, 0)], tm[:max(k, 0)], pol[:max(k, 0)], rew[:max(k, 0)]
+    k, cells, tm, pol, rew = merge(8)                          # 5 rows of rank 0, then 3 of rank 1
+    assert k == 8 and calls == [(0, 8), (1, 3)]
+    assert cells[:, 0].tolist() == [1] * 5 + [2] * 3
+    assert np.allclose(pol[:, 0], [0, .01, .02, .03, .04, 0, .01, .02])
+    assert rew[:, 0].tolist() == [0] * 5 + [1] * 3 and tm.tolist() == [0, 1, 0, 1, 0, 0, 1, 0]
+    k, cells, tm, pol, rew = merge(100)                        # the rest: rank 0 is empty, rank 1 has 4 left
+    assert k == 4 and cells[:, 0].tolist() == [2] * 4 and np.allclose(pol[:, 0], [.03, .04, .05, .06])
+    assert merge(100)[0] == 0
+    assert merge(0)[0] == 0
+    bad = (C.c_void_p * 2)(1, 3)
+    pending[0] = [0]
+    assert merge(10, bad)[0] == -4                             # the failing source's code comes back

@@ -216,3 +216,42 @@ def test_largest_board_and_longest_line():
     with torch.no_grad():
         rp, rv = torch_reference(N, Cs, blob, boards)
     assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
+
+
+def test_device_dirichlet_noise_follows_the_reference_sampler():
+    """The device's dirichlet(n, alpha = 0.05) (util.h:42-58: normalised std::gamma_distribution<float> draws) is
+    only defined as a distribution (the reference seeds from random_device).  alpha = 0.05 is the hard corner of
+    a gamma sampler (almost all mass near zero, a few components carry the sum), so the device draws of 4096
+    fresh roots are compared with the oracle's std::gamma_distribution draws: exact simplex constraint, the
+    moments of Dirichlet(alpha 1_k), and a two-sample Kolmogorov-Smirnov distance on the components and on the
+    largest component per draw."""
+    from scipy import stats
+    N, K, G = 9, 5, 4096
+    A = N * N
+    eng = capi.Engine(N, K, G, eval_mode=capi.AZ_EVAL_HASH, max_budget=4, noise_mode=capi.AZ_NOISE_DEVICE, seed=123)
+    eng.env_reset()
+    eng.search(1)                                       # fresh roots: every game draws its noise
+    dev = eng.get_noise().astype(np.float64)
+    st = 99
+    ref = np.empty((G, A))
+    for g in range(G):
+        x, st = azo.dirichlet(st, A)
+        ref[g] = x
+    assert np.isfinite(dev).all() and (dev >= 0).all()
+    assert np.abs(dev.sum(1) - 1.0).max() < 1e-5
+    assert len({tuple(np.round(r, 6)) for r in dev[:64]}) == 64          # games draw different noise
+    alpha, k = 0.05, A
+    var = (k - 1) / (k * k * (k * alpha + 1.0))                          # component of Dirichlet(alpha 1_k)
+    for name, x in (("device", dev), ("oracle", ref)):
+        assert abs(x.mean() - 1.0 / k) < 1e-9, name
+        assert abs(x.var() / var - 1.0) < 0.05, (name, x.var(), var)
+    # each position k of the draw is the same distribution (no lane- or index-dependent bias)
+    col = dev.mean(0)
+    assert np.abs(col - 1.0 / k).max() < 6 * np.sqrt(var / G)
+    d_comp = stats.ks_2samp(dev.ravel(), ref.ravel()).statistic
+    d_max = stats.ks_2samp(dev.max(1), ref.max(1)).statistic
+    frac_tiny = ((dev < 1e-12).mean(), (ref < 1e-12).mean())
+    print("KS components %.4f, KS max-component %.4f, fraction below 1e-12: device %.4f oracle %.4f" % ((d_comp, d_max) + frac_tiny))
+    assert d_comp < 0.01
+    assert d_max < 0.05
+    assert abs(frac_tiny[0] - frac_tiny[1]) < 0.01

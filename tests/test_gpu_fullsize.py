@@ -121,6 +121,36 @@ def test_selfplay_rows_are_consistent_full_size():
     assert np.allclose(s[first], 2 * budget / (2 * budget + 1.0), atol=2e-5)
 
 
+def test_config4_tower_20_blocks_256_channels_batch_8192():
+    """configs[4]: the 20-block x 256-channel tower (41 convolutions deep, per-layer kernels) at leaf batch
+    8192.  The first boards are those of the reference fixture (unmodified network.hpp, fp32): 1e-3 at full
+    batch; the rest through properties: finite, every policy a distribution, value pairs sum to 0, and the
+    big batch gives the bits of a 16-board call on the boards they share."""
+    N, Cs, B = 15, [256] * 21, 8192
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tower_n15_c256x21_sharp.npz"))
+    assert [int(c) for c in z["Cs"]] == Cs
+    nb = int(z["B"])
+    blob = synth.make_blob(N, 3, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]))
+    boards = synth.random_boards(B, N, seed=404)
+    boards[:nb] = z["boards"]
+    eng = capi.Engine(N, 5, B, Cs=Cs)
+    assert not eng.tower_is_fused()
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(boards)
+    assert np.isfinite(pol).all() and np.isfinite(val).all()
+    assert np.abs(pol.sum(1) - 1.0).max() < 1e-4 and (pol >= 0).all()
+    assert np.abs(val.sum(1)).max() < 1e-6 and np.abs(val).max() <= 1.0
+    perr, verr = np.abs(pol[:nb] - z["policy"]).max(), np.abs(val[:nb] - z["value"]).max()
+    print("20x256 tower at batch 8192 vs reference fixture: policy err %.3g value err %.3g" % (perr, verr))
+    assert perr < 1e-3 and verr < 1e-3
+    pol16, val16 = eng.tower_forward(boards[:16])
+    assert np.array_equal(pol16, pol[:16]) and np.array_equal(val16, val[:16])
+    # boards are independent: a permutation of the batch permutes the outputs
+    perm = np.random.default_rng(5).permutation(B)[:64]
+    polp, valp = eng.tower_forward(boards[perm])
+    assert np.array_equal(polp, pol[perm]) and np.array_equal(valp, val[perm])
+
+
 def test_selfplay_survives_a_peaked_policy_at_full_size():
     """15x15, 512 games, 800 sims/move with the heads sharpened 20x (a trained-network-like peaked policy:
     most of a move's visits sit under the move played, so most of the tree is kept across moves and the
