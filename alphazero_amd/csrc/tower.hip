@@ -763,6 +763,148 @@ __device__ __forceinline__ void fused_conv_taps(AccTile<J>& acc, int g, int tota
 #undef STAGE_W
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same wave tile on v_mfma_f32_16x16x32_{bf16,f16}: on random operands the chip holds a 12-14 % higher
+// clock on this shape than on 32x32x16 at (almost) the same cycles per FLOP (tools/microbench/mfma_shape.hip),
+// and the fused tower is power-limited, so this is the default shape.  A wave's 128 channels x 32 J positions
+// are 8 channel blocks x 2 J position blocks of 16 x 16, one k-step covers K = 32:
+//   T[a][b][r] = channel 16 a + 4 g + r, position 16 b + l15 of the wave's rows   (l15 = lane & 15, g = lane >> 4)
+//   A fragment (weights), block a: row 16 a + l15 of the tap's [128][128] image, 16-byte piece 4 ks + g
+//   B fragment (activations), block b: LDS row of position 16 b + l15 (+ the tap's offset), piece 4 ks + g
+// so a lane still holds four consecutive channels of one position, and both fragment reads are conflict-free
+// ds_read_b128 on the images the 32x32x16 path uses (16 rows x 16 distinct XOR-ed pieces; 16 rows of 272 B).
+// The MFMAs are inline asm with the accumulator tied in an AGPR quad: with the builtin the register allocator
+// copies accumulators around inside the loop.  What the compiler cannot see behind the asm is handled here:
+// wait states between the last MFMAs and the first read of their results, and between the epilogue's writes of
+// the accumulators and the first MFMA.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int J> using AccTile16 = f32x4[8][2 * J];
+
+template <int PR>
+__device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+    if constexpr (PR == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// every accumulator of the tile is in its AGPR quad from here on (an empty asm the values pass through)
+template <int J>
+__device__ __forceinline__ void acc_fence16(AccTile16<J>& T) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * J; ++b) asm volatile("" : "+a"(T[a][b]));
+}
+
+template <int J>
+__device__ __forceinline__ void fused_bias_init16(AccTile16<J>& T, const float* bptr, int g) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const float4 bv = *(const float4*)(bptr + 16 * a + 4 * g);
+#pragma unroll
+        for (int b = 0; b < 2 * J; ++b) { T[a][b][0] = bv.x; T[a][b][1] = bv.y; T[a][b][2] = bv.z; T[a][b][3] = bv.w; }
+    }
+}
+
+// fused_epi_hidden / fused_epi_residual in this layout (row0: the lane's position of block 0, + 8 g bytes)
+template <int PR, int J>
+__device__ __forceinline__ void fused_epi_hidden16(AccTile16<J>& Y, const float* next_bias, unsigned char* row0,
+                                                   const float (&caps)[2 * J], int g) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const float4 bv = *(const float4*)(next_bias + 16 * a + 4 * g);
+#pragma unroll
+        for (int b = 0; b < 2 * J; ++b) {
+            const float cap = caps[b];
+            uint2 o;
+            o.x = Prec<PR>::pack2(relu_cap(Y[a][b][0], cap), relu_cap(Y[a][b][1], cap));
+            o.y = Prec<PR>::pack2(relu_cap(Y[a][b][2], cap), relu_cap(Y[a][b][3], cap));
+            *(uint2*)(row0 + b * 16 * A_STRIDE + 32 * a) = o;
+            Y[a][b][0] = bv.x; Y[a][b][1] = bv.y; Y[a][b][2] = bv.z; Y[a][b][3] = bv.w;
+        }
+        if (a & 1) __builtin_amdgcn_sched_barrier(0);      // 32 values at a time: short live ranges
+    }
+}
+template <int PR, int J>
+__device__ __forceinline__ void fused_epi_residual16(AccTile16<J>& X, const float* next_bias, unsigned char* row0,
+                                                     const float (&caps)[2 * J], int g) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const float4 bv = *(const float4*)(next_bias + 16 * a + 4 * g);
+#pragma unroll
+        for (int b = 0; b < 2 * J; ++b) {
+            const float cap = caps[b];
+            const float r0 = relu_cap(X[a][b][0], cap), r1 = relu_cap(X[a][b][1], cap);
+            const float r2 = relu_cap(X[a][b][2], cap), r3 = relu_cap(X[a][b][3], cap);
+            uint2 o;
+            o.x = Prec<PR>::pack2(r0, r1);
+            o.y = Prec<PR>::pack2(r2, r3);
+            *(uint2*)(row0 + b * 16 * A_STRIDE + 32 * a) = o;
+            X[a][b][0] = r0 + bv.x; X[a][b][1] = r1 + bv.y; X[a][b][2] = r2 + bv.z; X[a][b][3] = r3 + bv.w;
+        }
+        if (a & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One 3x3 convolution accumulated onto `acc`: the weight stream, double buffer, swizzle and hand-over of
+// fused_conv_taps, with four k-steps of 32 per tap.  A k-step is 8 x 2 J MFMAs, channel block major; the
+// 8 + 2 J fragment reads of the NEXT k-step go one per gap behind its first MFMAs, in the order the next
+// k-step consumes them (activations, then weights by channel block), which leaves the last of them more than
+// a dozen MFMAs to return; the eight 4 KB pieces of the next tap's weights go out in k-steps 0 and 1, in the
+// second half of the step, away from the fragment reads.
+template <int PR, int J>
+__device__ __forceinline__ void fused_conv_taps16(AccTile16<J>& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
+                                                  __amdgpu_buffer_rsrc_t wrsrc, unsigned st_off, unsigned char* st_dst,
+                                                  int posrow16, int W, int gq, int l15) {
+    constexpr int NB = 2 * J;
+#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+        wrsrc, (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, st_off, (g_) * (128 * 128 * 2) + (p_) * 4096, 0, 0)
+    u32x4 fx[2][NB], fw[2][8];
+    const unsigned char* bA = sA + (posrow16 - W - 1) * A_STRIDE + gq * 16;        // tap 0: (-1,-1)
+    const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l15 * 256;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fx[0][b] = *(const u32x4*)(bA + b * 16 * A_STRIDE);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) fw[0][a] = *(const u32x4*)(bB + a * 16 * 256 + ((gq ^ l15) << 4));
+    acc_fence16<J>(acc);
+    asm volatile("s_nop 7");                                 // accumulator writes of the epilogue -> first MFMA
+    for (int tap = 0; tap < 9; ++tap, ++g) {
+        const int gn = g + 1 < total ? g + 1 : g;            // after the very last chunk: re-fetch it into the idle buffer
+        const int tn = tap < 8 ? tap + 1 : 8;
+        const unsigned char* nA = sA + (posrow16 + (tn / 3 - 1) * W + (tn % 3 - 1)) * A_STRIDE + gq * 16;
+        const unsigned char* nB = sB + ((g + 1) & 1) * W_BUF_BYTES + l15 * 256;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks & 1, n = c ^ 1;
+            const unsigned char* rA = ks < 3 ? bA + (ks + 1) * 64 : nA;
+            const unsigned char* rB = ks < 3 ? bB + ((((ks + 1) * 4 + gq) ^ l15) << 4) : nB + ((gq ^ l15) << 4);
+            if (ks == 3) {
+                // every wave holds its last fragments of this tap in registers and the next tap's weights
+                // have landed: hand the buffers over
+                AZ_DMA_LANDED();
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int m = a * NB + b;                // MFMA number inside the k-step
+                    mfma16<PR>(acc[a][b], fw[c][a], fx[c][b]);
+                    if (m < NB) fx[n][m] = *(const u32x4*)(rA + m * 16 * A_STRIDE);
+                    else if (m < NB + 8) fw[n][m - NB] = *(const u32x4*)(rB + (m - NB) * 16 * 256);
+                    if (ks < 2 && m >= 4 * NB && (m - 4 * NB) % NB == 0) {        // 4 pieces per k-step, NB MFMAs apart
+                        const int piece = 4 * ks + (m - 4 * NB) / NB;
+                        STAGE_W(gn, (g + 1) & 1, piece);
+                    }
+                }
+        }
+        bA = nA; bB = nB;
+    }
+#undef STAGE_W
+    asm volatile("s_nop 15\n\ts_nop 7");                     // last MFMAs -> first read of their results
+    acc_fence16<J>(acc);
+}
+
 // Register budget: 400 of the SIMD's 512 per lane (amdgpu_num_vgpr counts half of the unified
 // file) -- nothing spills, and a 64-register wave of the tree kernel can live on every SIMD
 // beside the tower's wave (its block needs 7.5 KB of LDS, the tower leaves 8.8 KB), so when a
@@ -771,7 +913,12 @@ __device__ __forceinline__ void fused_conv_taps(AccTile<J>& acc, int g, int tota
 #ifndef AZ_TOWER_REG_CAP
 #define AZ_TOWER_REG_CAP __attribute__((amdgpu_num_vgpr(224)))
 #endif
-template <int PR, int J>
+template <int J, int SH> struct TileOf;
+template <int J> struct TileOf<J, 32> { typedef f32x16 type[4][J]; };
+template <int J> struct TileOf<J, 16> { typedef f32x4 type[8][2 * J]; };
+
+// SH: MFMA shape of the convolutions, 16 = v_mfma_f32_16x16x32 (default), 32 = v_mfma_f32_32x32x16
+template <int PR, int J, int SH>
 __global__ void __launch_bounds__(256) AZ_TOWER_REG_CAP
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
@@ -793,6 +940,10 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, gq = lane >> 4;               // 16x16x32 shape: position / row inside a block, k quarter
+    constexpr int NPB = SH == 16 ? 2 * J : J;                // position blocks of a wave
+    constexpr int PBS = SH == 16 ? 16 : 32;                  // positions per block
+    const int lpos = SH == 16 ? l15 : l31;                   // this lane's position inside a block
     const int b0 = blockIdx.x * bpt;                         // first board of the tile
     const int nb_here = min(bpt, B - b0);
     const int rows_here = nb_here * P;                       // tile rows that belong to boards
@@ -861,18 +1012,34 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();
     TSTAMP(41);
 
-    AccTile<J> X, Y;     // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
-    fused_bias_init(X, sBias, h);                            // stem bias
+    typename TileOf<J, SH>::type X, Y;   // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
+    if constexpr (SH == 16) fused_bias_init16<J>(X, sBias, gq); else fused_bias_init(X, sBias, h);   // stem bias
 
     // which of this lane's positions are real board cells
-    float keepcap[J];
+    float keepcap[NPB];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int r = PW * wv + 32 * j + l31;
+    for (int j = 0; j < NPB; ++j) {
+        const int r = PW * wv + PBS * j + lpos;
         const int p = r % P;
         keepcap[j] = (r < rows_here && (p / W) < N && (p % W) < N) ? Prec<PR>::cap() : 0.f;
     }
 
+    if constexpr (SH == 16) {
+        // stem: the im2col tile is exactly one k-step of 32
+        u32x4 xb[NPB], wa[8];
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) xb[b] = *(const u32x4*)(sI + (PW * wv + 16 * b + l15) * I_STRIDE + gq * 16);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) wa[a] = *(const u32x4*)(sW + (16 * a + l15) * I_STRIDE + gq * 16);
+        acc_fence16<J>(X);
+        asm volatile("s_nop 7");
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < NPB; ++b) mfma16<PR>(X[a][b], wa[a], xb[b]);
+        asm volatile("s_nop 15\n\ts_nop 7");
+        acc_fence16<J>(X);
+    } else
     // stem: 2 k-steps of 16 over the im2col tile
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -890,9 +1057,14 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();                                         // every wave is done with sI / sW
     TSTAMP(42);
     // bias table: [0] stem, [1 + L] convolution L.  Block b = convolutions 2b (onto Y) and 2b+1 (onto X).
-    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + l31) * A_STRIDE + 8 * h;
-    fused_epi_residual<PR, J>(X, sBias + 2 * 128, row0, keepcap, h);
-    fused_bias_init(Y, sBias + 1 * 128, h);
+    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + lpos) * A_STRIDE + 8 * (SH == 16 ? gq : h);
+    if constexpr (SH == 16) {
+        fused_epi_residual16<PR, J>(X, sBias + 2 * 128, row0, keepcap, gq);
+        fused_bias_init16<J>(Y, sBias + 1 * 128, gq);
+    } else {
+        fused_epi_residual<PR, J>(X, sBias + 2 * 128, row0, keepcap, h);
+        fused_bias_init(Y, sBias + 1 * 128, h);
+    }
 
     // weight stream set-up (see fused_conv_taps): piece p (0..7) of a chunk is 256 lanes x 16 B;
     // lane's piece index q = p*256 + tid -> LDS row q>>4 = p*16 + (tid>>4), physical piece tid&15,
@@ -912,20 +1084,24 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();
     TSTAMP(1);
 
-    const int posrow0 = Gd + PW * wv + l31;
+    const int posrow0 = Gd + PW * wv + lpos;
     const int n_blocks = n_layers >> 1;
     for (int b = 0; b < n_blocks; ++b) {
         // next block's biases; after the last block X restarts from the zero row: the heads read relu(x) itself
         const int nb1 = min(3 + 2 * b, n_layers), nb2 = b + 1 < n_blocks ? 4 + 2 * b : n_layers + 1;
-        fused_conv_taps<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
+        if constexpr (SH == 16) fused_conv_taps16<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, gq, l15);
+        else fused_conv_taps<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         // (the barrier before the last k-step: all waves have finished reading this layer's input)
         TSTAMP(2 + 4 * b);
-        fused_epi_hidden<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, h);
+        if constexpr (SH == 16) fused_epi_hidden16<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, gq);
+        else fused_epi_hidden<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, h);
         __syncthreads();
         TSTAMP(3 + 4 * b);
-        fused_conv_taps<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
+        if constexpr (SH == 16) fused_conv_taps16<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, gq, l15);
+        else fused_conv_taps<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         TSTAMP(4 + 4 * b);
-        fused_epi_residual<PR, J>(X, sBias + nb2 * 128, row0, keepcap, h);
+        if constexpr (SH == 16) fused_epi_residual16<PR, J>(X, sBias + nb2 * 128, row0, keepcap, gq);
+        else fused_epi_residual<PR, J>(X, sBias + nb2 * 128, row0, keepcap, h);
         __syncthreads();
         TSTAMP(5 + 4 * b);
     }
@@ -952,9 +1128,39 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         // Both 1x1 convolutions straight from the fp32 residual tile X (= relu(x), the last epilogue added a
         // zero bias): a lane holds 64 of the 128 channels of each of its J positions, the other half sits in
         // lane ^ 32.  Nothing is rounded to 16 bits between the last ResBlock and the heads.
-        f32x2 spv[J];
+        f32x2 spv[NPB];
 #pragma unroll
-        for (int j = 0; j < J; ++j) spv[j] = (f32x2){0.f, 0.f};
+        for (int j = 0; j < NPB; ++j) spv[j] = (f32x2){0.f, 0.f};
+        if constexpr (SH == 16) {
+            // a lane holds 32 of the 128 channels of each of its positions (16 a + 4 gq + r); lanes ^ 16, ^ 32 the rest
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float4 w01 = *(const float4*)(hp + 2 * (16 * a + 4 * gq));
+                const float4 w23 = *(const float4*)(hp + 2 * (16 * a + 4 * gq) + 4);
+#pragma unroll
+                for (int j = 0; j < NPB; ++j) {
+                    const float x0 = X[a][j][0], x1 = X[a][j][1], x2 = X[a][j][2], x3 = X[a][j][3];
+                    spv[j] += (f32x2){x0, x0} * (f32x2){w01.x, w01.y};
+                    spv[j] += (f32x2){x1, x1} * (f32x2){w01.z, w01.w};
+                    spv[j] += (f32x2){x2, x2} * (f32x2){w23.x, w23.y};
+                    spv[j] += (f32x2){x3, x3} * (f32x2){w23.z, w23.w};
+                }
+            }
+            TSTAMP(43);
+#pragma unroll
+            for (int j = 0; j < NPB; ++j) {
+                float lp = spv[j].x + __shfl_xor(spv[j].x, 16, 64);
+                float lv = spv[j].y + __shfl_xor(spv[j].y, 16, 64);
+                lp += __shfl_xor(lp, 32, 64);
+                lv += __shfl_xor(lv, 32, 64);
+                if (gq == 0) {
+                    const int row = PW * wv + 16 * j + l15;
+                    const bool real = keepcap[j] != 0.f;
+                    s_logit[row] = real ? lp + bp : -3.4e38f;
+                    s_u[row] = real ? fmaxf(lv + bvv, 0.f) : 0.f;
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -982,6 +1188,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                 s_logit[row] = real ? lp + bp : -3.4e38f;
                 s_u[row] = real ? fmaxf(lv + bvv, 0.f) : 0.f;
             }
+        }
         }
         if (TM < 256 && tid < 256 - TM) { s_logit[TM + tid] = -3.4e38f; s_u[TM + tid] = 0.f; }
         for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
@@ -1159,8 +1366,10 @@ extern "C" int az_tower_configure(void) {
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
-    SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
-    SETA((az_tower_fused_kernel<0, 1>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 2, 32>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2, 32>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 1, 32>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1, 32>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 2, 16>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2, 16>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 1, 16>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1, 16>), 160 * 1024);
 #undef SETA
     return (int)e;
 }
@@ -1209,13 +1418,15 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     const int bpt = rows / P;
     const int tiles = (B + bpt - 1) / bpt;
     const size_t sm = az_tower_fused_lds_bytes(N, n_layers, rows);
-    if (rows == 128) {
-        if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, 1>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
-        else hipLaunchKernelGGL((az_tower_fused_kernel<0, 1>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
-    } else {
-        if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, 2>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
-        else hipLaunchKernelGGL((az_tower_fused_kernel<0, 2>), dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt);
-    }
+    const char* shape = getenv("AZ_MFMA_SHAPE");             // "32": the 32x32x16 build of the kernel (A/B and tests)
+    const bool s32 = shape && atoi(shape) == 32;
+#define FUSED_ARGS dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt
+#define FUSED_LAUNCH(J_, SH_) do { if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, J_, SH_>), FUSED_ARGS); \
+                                   else hipLaunchKernelGGL((az_tower_fused_kernel<0, J_, SH_>), FUSED_ARGS); } while (0)
+    if (rows == 128) { if (s32) FUSED_LAUNCH(1, 32); else FUSED_LAUNCH(1, 16); }
+    else { if (s32) FUSED_LAUNCH(2, 32); else FUSED_LAUNCH(2, 16); }
+#undef FUSED_LAUNCH
+#undef FUSED_ARGS
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
