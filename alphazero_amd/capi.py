@@ -26,6 +26,9 @@ EXPORTS = [
     "az_group_create", "az_group_destroy", "az_group_contexts", "az_group_context", "az_group_load_weights",
     "az_group_selfplay_begin", "az_group_selfplay_run", "az_group_sync", "az_group_replay_drain", "az_group_get_stats",
     "az_ctx_cells", "az_merge_drain", "az_device_count", "az_get_noise",
+    "az_blokus_create", "az_blokus_destroy", "az_blokus_reset", "az_blokus_step", "az_blokus_legal_mask", "az_blokus_boards",
+    "az_blokus_state", "az_blokus_playout", "az_blokus_sync", "az_blokus_stream", "az_blokus_orient", "az_blokus_host_state_size",
+    "az_blokus_host_reset", "az_blokus_host_step", "az_blokus_host_legal", "az_blokus_host_info",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
@@ -113,6 +116,9 @@ def load():
         L.az_tower_forward_static.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.az_tower_static_max_batch.restype = C.c_size_t
         L.az_tower_static_max_batch.argtypes = [C.c_void_p]
+        L.az_blokus_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int]
+        L.az_blokus_host_state_size.restype = C.c_size_t
+        L.az_blokus_stream.restype = C.c_void_p
         _lib = L
     return _lib
 
@@ -353,3 +359,89 @@ def replay_symmetries(N, cells, to_move, policy):
     po = np.empty((8, N, N), np.float32)
     _chk(load().az_replay_symmetries(N, _ptr(cells), int(to_move), _ptr(policy), _ptr(so), _ptr(po)))
     return so, po
+
+
+class Blokus:
+    """G lockstep Blokus games on one GPU (az_blokus_*): 20x20, four players, 91 orientations,
+    action = o * 400 + y * 20 + x, planes u8 [5,20,20], reward f32 [4]."""
+    N, ORIENTS, CELLS, ACTIONS, PLAYERS, PLANES = 20, 91, 400, 91 * 400, 4, 5
+
+    def __init__(self, G, device=0, seed=0, game_slot_base=0):
+        self.G = G
+        self.h = C.c_void_p()
+        _chk(load().az_blokus_create(C.byref(self.h), device, G, seed, game_slot_base))
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().az_blokus_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        _chk(load().az_blokus_reset(self.h))
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, np.int32)
+        reward = np.empty((self.G, 4), np.float32)
+        done = np.empty(self.G, np.uint8)
+        _chk(load().az_blokus_step(self.h, _ptr(actions), _ptr(reward), _ptr(done)))
+        return reward, done
+
+    def legal_mask(self, want_mask=True):
+        mask = np.empty((self.G, self.ACTIONS), np.uint8) if want_mask else None
+        count = np.empty(self.G, np.int32)
+        _chk(load().az_blokus_legal_mask(self.h, _ptr(mask) if want_mask else None, _ptr(count)))
+        return mask, count
+
+    def boards(self):
+        pl = np.empty((self.G, self.PLANES, self.N, self.N), np.uint8)
+        _chk(load().az_blokus_boards(self.h, _ptr(pl)))
+        return pl
+
+    def state(self):
+        tm, over = np.empty(self.G, np.uint8), np.empty(self.G, np.uint8)
+        moves = np.empty(self.G, np.int32)
+        used = np.empty((self.G, 4), np.uint32)
+        fr = np.empty((self.G, 4), np.float32)
+        _chk(load().az_blokus_state(self.h, _ptr(tm), _ptr(over), _ptr(moves), _ptr(used), _ptr(fr)))
+        return dict(to_move=tm, over=over, moves=moves, used=used, final_reward=fr)
+
+    def playout(self, steps):
+        _chk(load().az_blokus_playout(self.h, int(steps)))
+
+    def sync(self):
+        _chk(load().az_blokus_sync(self.h))
+
+
+def blokus_orient(o):
+    piece, h, w = C.c_int(), C.c_int(), C.c_int()
+    cells = np.zeros((5, 2), np.int8)
+    n = _chk(load().az_blokus_orient(int(o), C.byref(piece), C.byref(h), C.byref(w), _ptr(cells)))
+    return piece.value, h.value, w.value, [tuple(int(v) for v in c) for c in cells[:n]]
+
+
+class BlokusHost:
+    """One Blokus game on the host (the library's CPU twin of its device rules; no GPU needed)."""
+
+    def __init__(self):
+        self.buf = C.create_string_buffer(load().az_blokus_host_state_size())
+        _chk(load().az_blokus_host_reset(self.buf))
+
+    def step(self, action):
+        rew = np.zeros(4, np.float32)
+        done = _chk(load().az_blokus_host_step(self.buf, int(action), _ptr(rew)))
+        return rew, done
+
+    def legal(self):
+        mask = np.zeros(91 * 400, np.uint8)
+        n = _chk(load().az_blokus_host_legal(self.buf, _ptr(mask)))
+        return mask, n
+
+    def info(self):
+        cells = np.zeros(400, np.uint8)
+        tm, over = C.c_int(), C.c_int()
+        used = np.zeros(4, np.uint32)
+        scores = np.zeros(4, np.int32)
+        _chk(load().az_blokus_host_info(self.buf, _ptr(cells), C.byref(tm), C.byref(over), _ptr(used), _ptr(scores)))
+        return dict(cells=cells, to_move=tm.value, over=bool(over.value), used=used, scores=scores)

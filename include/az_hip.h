@@ -214,6 +214,40 @@ int az_merge_drain(int n_src, az_drain_fn fn, void* const* srcs, int A, int cap,
                    uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
 int az_ctx_cells(const az_ctx*);                  /* N*N of the context's board */
 
+/* ---- Blokus: 20x20, four players, 21 polyominoes each (rules stated in alphazero_amd/csrc/az_blokus_rules.h).
+ * The reference names a Blokus environment (.gitmodules:7-9) without shipping it and its MCTS cannot drive
+ * four players (replay.hpp:127, mcts.hpp:431), so these are the Env members of the call sites
+ * (mcts.hpp:251-271,427; generate.cpp:75,103) for G lockstep games, on the rules this library defines:
+ * action = o*400 + y*20 + x (orientation o of 91, bounding-box corner at row y, column x), policy layout
+ * [91,20,20], planes u8 [5,20,20] (squares of players 0..3, player to move), reward f32 [4] by player. */
+typedef struct az_blokus az_blokus;
+int az_blokus_create(az_blokus** out, int device, int G, uint64_t seed, int game_slot_base);
+int az_blokus_destroy(az_blokus*);
+int az_blokus_reset(az_blokus*);                                                 /* Env::reset */
+/* Env::step: actions i32 [G] (-1 = leave the game alone) -> reward f32 [G,4], done u8 [G] */
+int az_blokus_step(az_blokus*, const int32_t* actions, float* reward, uint8_t* done);
+/* Env::possible_actions of the player to move: mask u8 [G,91,20,20] (or NULL), count i32 [G] (or NULL) */
+int az_blokus_legal_mask(az_blokus*, uint8_t* mask, int32_t* count);
+int az_blokus_boards(az_blokus*, uint8_t* planes /* [G,5,20,20] */);             /* Env::get_board */
+/* Env::get_player and bookkeeping (any pointer may be NULL): to_move u8 [G], over u8 [G], pieces placed
+ * i32 [G], pieces-played masks u32 [G,4], final reward f32 [G,4] */
+int az_blokus_state(az_blokus*, uint8_t* to_move, uint8_t* over, int32_t* moves, uint32_t* used, float* final_reward);
+/* `steps` uniformly random legal moves per unfinished game, on the device (asynchronous): the k-th legal
+ * action in index order, k = (u * count) >> 32, u = Philox4x32-10(seed, stream game_slot_base + g,
+ * counter = pieces placed) word 0.  The env-only workload of the measurements. */
+int az_blokus_playout(az_blokus*, int steps);
+int az_blokus_sync(az_blokus*);
+void* az_blokus_stream(az_blokus*);
+/* the orientation table: piece, bounding box, cells (row, column) row-major; returns the number of cells */
+int az_blokus_orient(int o, int* piece, int* h, int* w, int8_t* cells_yx /* [5][2] */);
+/* the same rules on the host, one game in caller memory of az_blokus_host_state_size() bytes (C++ Env shim,
+ * CPU tests): step returns 1 done, 0 running, AZ_E_ARG illegal; legal returns the count */
+size_t az_blokus_host_state_size(void);
+int az_blokus_host_reset(void* state);
+int az_blokus_host_step(void* state, int action, float* reward /* [4] */);
+int az_blokus_host_legal(const void* state, uint8_t* mask /* [91*400] or NULL */);
+int az_blokus_host_info(const void* state, uint8_t* cells /* [400] */, int* to_move, int* over, uint32_t* used /* [4] */, int32_t* scores /* [4] */);
+
 /* Env::step on the host (the rules the C++ Env shim and az_env_load use; same
  * rules as the device kernels): returns 1 done, 0 running, AZ_E_ARG illegal. */
 int az_host_env_step(int N, int K, uint8_t* cells, int* to_move, int action, float* reward);

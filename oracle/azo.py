@@ -32,6 +32,7 @@ def lib():
         L.azo_tower_blob_size.restype = C.c_size_t
         L.azo_mcts_eval_count.restype = C.c_long
         L.azo_philox_u32.restype = C.c_uint32
+        L.azo_blokus_new.restype = C.c_void_p
         L.azo_philox_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         _LIB = L
     return _LIB
@@ -247,3 +248,71 @@ def canonical_tree(d):
     """Tuple form of a BFS dump for exact comparison."""
     return [(int(a), int(b), int(c), float(e), float(f), int(g)) for a, b, c, e, f, g in
             zip(d["parent"], d["action"], d["n"], d["v"], d["p"], d["kind"])]
+
+
+class Blokus:
+    """One Blokus game of the oracle (oracle/blokus_oracle.cpp): 20x20, four players, 91 orientations,
+    action = o * 400 + y * 20 + x."""
+    N, ORIENTS, ACTIONS, PLAYERS = 20, 91, 91 * 400, 4
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().azo_blokus_new())
+
+    @staticmethod
+    def orient(o):
+        piece, h, w = C.c_int(), C.c_int(), C.c_int()
+        cells = np.zeros((5, 2), np.int8)
+        n = lib().azo_blokus_orient(int(o), C.byref(piece), C.byref(h), C.byref(w), _p(cells, C.c_int8))
+        return piece.value, h.value, w.value, [tuple(int(v) for v in c) for c in cells[:n]]
+
+    def reset(self):
+        lib().azo_blokus_reset(self.h)
+
+    def step(self, action):
+        rew = np.zeros(4, np.float32)
+        done = lib().azo_blokus_step(self.h, int(action), _p(rew, C.c_float))
+        return rew, done
+
+    def random_move(self, seed, stream, counter):
+        rew = np.zeros(4, np.float32)
+        done = C.c_int()
+        a = lib().azo_blokus_random_move(self.h, C.c_uint64(seed), C.c_uint32(stream), C.c_uint32(counter), _p(rew, C.c_float), C.byref(done))
+        return a, rew, done.value
+
+    def legal(self):
+        mask = np.zeros(self.ACTIONS, np.uint8)
+        n = lib().azo_blokus_legal(self.h, _p(mask, C.c_uint8))
+        return mask, n
+
+    def cells(self):
+        c = np.zeros(400, np.uint8)
+        lib().azo_blokus_cells(self.h, _p(c, C.c_uint8))
+        return c
+
+    def planes(self):
+        pl = np.zeros((5, 20, 20), np.uint8)
+        lib().azo_blokus_planes(self.h, _p(pl, C.c_uint8))
+        return pl
+
+    def used(self):
+        u = np.zeros(4, np.uint32)
+        lib().azo_blokus_used(self.h, _p(u, C.c_uint32))
+        return u
+
+    def scores(self):
+        s = np.zeros(4, np.int32)
+        lib().azo_blokus_scores(self.h, _p(s, C.c_int32))
+        return s
+
+    @property
+    def to_move(self):
+        return lib().azo_blokus_to_move(self.h)
+
+    @property
+    def over(self):
+        return bool(lib().azo_blokus_over(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().azo_blokus_free(self.h)
+            self.h = None
