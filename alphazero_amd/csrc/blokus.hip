@@ -4,14 +4,15 @@
 // generate.cpp:75,103); the reference's own Blokus source is absent, so the rules are this build's.
 //
 // State in HBM, structure-of-arrays over the games: per player 20 row bit boards (u32, bit x = column x),
-// the pieces-played masks, and -- kept current for the player to move -- the legal-action set as a bit set
-// [91 orientations][448 bits] (bit y*20+x of orientation o = action o*400 + y*20 + x) with its count.
-// Legality of (o, y, x) for player q is three bit tests per piece row against two derived boards:
-//   forbidden[r] = every occupied cell | cells edge-adjacent to q's squares
-//   contact[r]   = cells diagonal to q's squares (q's start corner before q's first piece)
-//   legal  <=>  piece unused, inside the board, rows & forbidden == 0 for all rows, rows & contact != 0 for one
-// A scan tests all 91 x 400 placements: each lane owns 7 anchor cells, the orientation loop is wave-uniform
-// (piece rows come from constant memory through scalar loads), one ballot per 64 anchors gathers the bits.
+// the pieces-played masks, and -- kept current for the player to move -- the legal-action set as row masks
+// [91 orientations][20 rows] (bit x of word (o, y) = action o*400 + y*20 + x) with its count.
+// Legality for player q comes from two derived boards,
+//   free[r]    = cells that are empty and not edge-adjacent to q's squares
+//   contact[r] = cells diagonal to q's squares (q's start corner before q's first piece)
+// and is evaluated for a whole board row at a time: for orientation o anchored in row y, with cells (cy, cx),
+//   legal_x(o, y) = AND_cells (free[y + cy] >> cx)  &  OR_cells (contact[y + cy] >> cx)
+// (a shifted-in zero is an off-board cell), so one lane settles 20 placements in about eight operations per
+// piece cell; the 91 x 20 (orientation, row) pairs are strided over the 64 lanes, the counts come from popcounts.
 #include "../../include/az_hip.h"
 #include "az_blokus_rules.h"
 #include "az_dev.h"
@@ -24,7 +25,7 @@
 
 extern "C" int az_internal_fail(int code, const char* msg);
 
-#define AZB_WORDS 14                                   // u32 words of one orientation's bit set (448 >= 400 bits)
+#define AZB_WORDS AZB_N                                // one u32 row mask per board row of an orientation
 #define AZB_SET_WORDS (AZB_ORIENTS * AZB_WORDS)
 
 __constant__ AzbOrient c_orient[AZB_ORIENTS];
@@ -41,84 +42,113 @@ struct AzbDev {
     uint8_t*  over;         // [G]
     int*      moves;        // [G] pieces placed so far
     int*      legal_count;  // [G] legal actions of the player to move (0 once over)
-    uint32_t* legal_bits;   // [G][91][14]
+    uint32_t* legal_bits;   // [G][91][20] row masks
     float*    final_reward; // [G][4]
 };
 
 // ---------------------------------------------------------------------------------------------- device
-// Legal-action set of player q on the position in s_own: fills s_bits [91][14] and s_cnt [91]; returns the
+// The orientation table in LDS, 8 bytes each: x = piece | h << 8 | n << 16 | cell0 << 24, y = cells 1..4, a cell
+// as cy << 4 | cx (lanes index it by different orientations: LDS serves that, the constant cache would not).
+__device__ void azb_load_table(uint2* s_tab) {
+    for (int o = threadIdx.x; o < AZB_ORIENTS; o += 64) {
+        uint32_t c[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < c_orient[o].n; ++i) c[i] = (uint32_t)(c_orient[o].cy[i] << 4 | c_orient[o].cx[i]);
+        s_tab[o] = make_uint2(c_orient[o].piece | (uint32_t)c_orient[o].h << 8 | (uint32_t)c_orient[o].n << 16 | c[0] << 24,
+                              c[1] | c[2] << 8 | c[3] << 16 | c[4] << 24);
+    }
+    __syncthreads();
+}
+
+// per-orientation counts of a legal set
+__device__ void azb_count(const uint32_t* s_bits, int* s_cnt) {
+    for (int o = threadIdx.x; o < AZB_ORIENTS; o += 64) {
+        int c = 0;
+        for (int y = 0; y < AZB_N; ++y) c += __popc(s_bits[o * AZB_WORDS + y]);
+        s_cnt[o] = c;
+    }
+    __syncthreads();
+}
+
+// Legal-action set of player q on the position in s_own: fills s_bits [91][20] and s_cnt [91]; returns the
 // total.  All 64 lanes take part.
-__device__ int azb_scan(const uint32_t* s_own, uint32_t used_q, int q, uint32_t* s_forb, uint32_t* s_contact,
+__device__ int azb_scan(const uint32_t* s_own, uint32_t used_q, int q, uint2* s_rows, const uint2* s_tab,
                         uint32_t* s_bits, int* s_cnt) {
     const int lane = threadIdx.x;
+    const uint32_t full = (1u << AZB_N) - 1u;
     if (lane < AZB_N) {
         const int r = lane;
-        const uint32_t full = (1u << AZB_N) - 1u;
         const uint32_t mine = s_own[q * AZB_N + r];
         const uint32_t up = r > 0 ? s_own[q * AZB_N + r - 1] : 0u, dn = r < AZB_N - 1 ? s_own[q * AZB_N + r + 1] : 0u;
         const uint32_t occ = s_own[r] | s_own[AZB_N + r] | s_own[2 * AZB_N + r] | s_own[3 * AZB_N + r];
-        s_forb[r] = (occ | (mine << 1) | (mine >> 1) | up | dn) & full;
+        const uint32_t forb = occ | (mine << 1) | (mine >> 1) | up | dn;
         uint32_t c = ((up << 1) | (up >> 1) | (dn << 1) | (dn >> 1)) & full;
         if (used_q == 0u) {                                          // first piece: the player's own corner
             const int cy = q < 2 ? 0 : AZB_N - 1, cx = (q == 0 || q == 3) ? 0 : AZB_N - 1;
             c = r == cy ? 1u << cx : 0u;
         }
-        s_contact[r] = c;
+        s_rows[r] = make_uint2(~forb & full, c);
     }
     __syncthreads();
-    int ay[7], ax[7];
-#pragma unroll
-    for (int t = 0; t < 7; ++t) { const int i = lane + 64 * t; ay[t] = i / AZB_N; ax[t] = i - AZB_N * ay[t]; }
     int total = 0;
-    for (int o = 0; o < AZB_ORIENTS; ++o) {
-        const int piece = c_orient[o].piece, h = c_orient[o].h, w = c_orient[o].w;
-        int cnt = 0;
-        if (used_q >> piece & 1u) {
-            if (lane < AZB_WORDS) s_bits[o * AZB_WORDS + lane] = 0u;
-        } else {
-            uint32_t rows[5];
+    for (int i = lane; i < AZB_SET_WORDS; i += 64) {
+        const int o = i / AZB_N, y = i - AZB_N * o;
+        const uint2 tab = s_tab[o];
+        const int piece = tab.x & 0xFF, h = tab.x >> 8 & 0xFF, n = tab.x >> 16 & 0xFF;
+        uint32_t mask = 0u;
+        if (!(used_q >> piece & 1u) && y + h <= AZB_N) {
+            const unsigned long long cells = (unsigned long long)(tab.x >> 24) | (unsigned long long)tab.y << 8;
+            uint32_t fit = full, touch = 0u;
 #pragma unroll
-            for (int r = 0; r < 5; ++r) rows[r] = c_orient[o].rows[r];
-#pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const int y = ay[t], x = ax[t];
-                bool ok = y + h <= AZB_N && x + w <= AZB_N;           // also false for the anchors past cell 399 (y >= 20)
-                uint32_t touch = 0u;
-#pragma unroll
-                for (int r = 0; r < 5; ++r)
-                    if (r < h) {
-                        const int row = min(y + r, AZB_N - 1);
-                        const uint32_t m = rows[r] << x;
-                        ok = ok && (m & s_forb[row]) == 0u;
-                        touch |= m & s_contact[row];
-                    }
-                const unsigned long long b = __ballot(ok && touch != 0u);
-                cnt += __popcll(b);
-                if (lane == 0) { s_bits[o * AZB_WORDS + 2 * t] = (uint32_t)b; s_bits[o * AZB_WORDS + 2 * t + 1] = (uint32_t)(b >> 32); }
-            }
+            for (int k = 0; k < 5; ++k)
+                if (k < n) {
+                    const int c = (int)(cells >> (8 * k)) & 0xFF;
+                    const uint2 rw = s_rows[y + (c >> 4)];
+                    fit &= rw.x >> (c & 15);
+                    touch |= rw.y >> (c & 15);
+                }
+            mask = fit & touch;
         }
-        if (lane == 0) s_cnt[o] = cnt;
-        total += cnt;
+        s_bits[i] = mask;
+        total += __popc(mask);
     }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) total += __shfl_xor(total, o2, 64);
     __syncthreads();
+    azb_count(s_bits, s_cnt);
     return total;
 }
 
-// The k-th legal action in index order (k < total), from s_bits / s_cnt.
+// The k-th legal action in index order (k < total), from s_bits / s_cnt, by the whole wave: an inclusive scan
+// over the orientation counts (two trips of 64) finds the orientation, a scan over its 20 row popcounts the
+// row, a few bit clears the column.  Every lane returns the action.
 __device__ int azb_kth_action(const uint32_t* s_bits, const int* s_cnt, int k) {
-    int o = 0;
-    while (k >= s_cnt[o]) { k -= s_cnt[o]; ++o; }
-    int wd = 0;
-    for (;; ++wd) { const int c = __popc(s_bits[o * AZB_WORDS + wd]); if (k < c) break; k -= c; }
-    uint32_t v = s_bits[o * AZB_WORDS + wd];
+    const int lane = threadIdx.x;
+    int o = -1;
+    for (int base = 0; base < AZB_ORIENTS && o < 0; base += 64) {
+        int x = base + lane < AZB_ORIENTS ? s_cnt[base + lane] : 0;
+        const int own = x;
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        const unsigned long long hit = __ballot(x > k);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;
+            o = base + l;
+            k -= __shfl(x - own, l, 64);                     // actions before orientation o
+        } else k -= __shfl(x, 63, 64);
+    }
+    int x = lane < AZB_N ? __popc(s_bits[o * AZB_WORDS + lane]) : 0;
+    const int own = x;
+    for (int d = 1; d < 32; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    const unsigned long long hit = __ballot(lane < AZB_N && x > k);
+    const int y = __ffsll((long long)hit) - 1;
+    k -= __shfl(x - own, y, 64);
+    uint32_t v = s_bits[o * AZB_WORDS + y];
     for (; k > 0; --k) v &= v - 1u;
-    return o * AZB_CELLS + 32 * wd + (__ffs((int)v) - 1);
+    return o * AZB_CELLS + AZB_N * y + (__ffs((int)v) - 1);
 }
 
 // Places `action` (known legal) for the player to move, then hands the turn to the next player who can move,
 // or ends the game.  s_own / s_used / s_last / s_meta {to_move, over, pieces placed, legal count} hold the
 // game (and stay current, so a kernel can play on without re-reading HBM); the state arrays are updated too.
-__device__ void azb_play(const AzbDev& d, int g, int action, uint32_t* s_own, uint32_t* s_forb, uint32_t* s_contact,
+__device__ void azb_play(const AzbDev& d, int g, int action, uint32_t* s_own, uint2* s_rows, const uint2* s_tab,
                          uint32_t* s_bits, int* s_cnt, uint32_t* s_used, int* s_last, int* s_meta, float* reward, uint8_t* done) {
     const int lane = threadIdx.x;
     const int p = s_meta[0];
@@ -130,7 +160,7 @@ __device__ void azb_play(const AzbDev& d, int g, int action, uint32_t* s_own, ui
     int next = -1, cnt = 0;
     for (int k = 1; k <= AZB_PLAYERS; ++k) {
         const int q = (p + k) & 3;
-        cnt = azb_scan(s_own, s_used[q], q, s_forb, s_contact, s_bits, s_cnt);
+        cnt = azb_scan(s_own, s_used[q], q, s_rows, s_tab, s_bits, s_cnt);
         if (cnt > 0) { next = q; break; }
     }
     // write the position back: only player p's rows and masks changed
@@ -164,7 +194,7 @@ __device__ void azb_play(const AzbDev& d, int g, int action, uint32_t* s_own, ui
 }
 
 #define AZB_SMEM_DECL \
-    __shared__ uint32_t s_own[4 * AZB_N]; __shared__ uint32_t s_forb[AZB_N]; __shared__ uint32_t s_contact[AZB_N]; \
+    __shared__ uint32_t s_own[4 * AZB_N]; __shared__ uint2 s_rows[AZB_N]; __shared__ uint2 s_tab[AZB_ORIENTS]; \
     __shared__ uint32_t s_bits[AZB_SET_WORDS]; __shared__ int s_cnt[AZB_ORIENTS]; __shared__ uint32_t s_used[4]; \
     __shared__ int s_last[4]; __shared__ int s_meta[4]
 
@@ -183,7 +213,8 @@ extern "C" __global__ void __launch_bounds__(64) azb_reset_kernel(AzbDev d) {
     for (int i = lane; i < 4 * AZB_N; i += 64) { s_own[i] = 0u; d.own[(size_t)g * 4 * AZB_N + i] = 0u; }
     if (lane < 4) { s_used[lane] = 0u; d.used[g * 4 + lane] = 0u; d.last_piece[g * 4 + lane] = 0xFF; d.final_reward[g * 4 + lane] = 0.f; }
     __syncthreads();
-    const int cnt = azb_scan(s_own, 0u, 0, s_forb, s_contact, s_bits, s_cnt);
+    azb_load_table(s_tab);
+    const int cnt = azb_scan(s_own, 0u, 0, s_rows, s_tab, s_bits, s_cnt);
     for (int i = lane; i < AZB_SET_WORDS; i += 64) d.legal_bits[(size_t)g * AZB_SET_WORDS + i] = s_bits[i];
     if (lane == 0) { d.to_move[g] = 0; d.over[g] = 0; d.moves[g] = 0; d.legal_count[g] = cnt; }
 }
@@ -200,11 +231,12 @@ azb_step_kernel(AzbDev d, const int* actions, float* reward, uint8_t* done, int*
     bool ok = action < AZB_ACTIONS && !d.over[g];
     if (ok) {
         const int o = action / AZB_CELLS, cell = action % AZB_CELLS;
-        ok = d.legal_bits[(size_t)g * AZB_SET_WORDS + o * AZB_WORDS + (cell >> 5)] >> (cell & 31) & 1u;
+        ok = d.legal_bits[(size_t)g * AZB_SET_WORDS + o * AZB_WORDS + cell / AZB_N] >> (cell % AZB_N) & 1u;
     }
     if (!ok) { if (lane == 0) atomicAdd(illegal, 1); return; }
+    azb_load_table(s_tab);
     azb_load(d, g, s_own, s_used, s_last, s_meta);
-    azb_play(d, g, action, s_own, s_forb, s_contact, s_bits, s_cnt, s_used, s_last, s_meta, reward, done);
+    azb_play(d, g, action, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta, reward, done);
 }
 
 // `steps` uniformly random legal moves per game, entirely on the device: the k-th legal action in index
@@ -215,24 +247,19 @@ extern "C" __global__ void __launch_bounds__(64) azb_playout_kernel(AzbDev d, in
     const int g = blockIdx.x, lane = threadIdx.x;
     if (d.over[g]) return;
     azb_load(d, g, s_own, s_used, s_last, s_meta);
+    azb_load_table(s_tab);
     for (int i = lane; i < AZB_SET_WORDS; i += 64) s_bits[i] = d.legal_bits[(size_t)g * AZB_SET_WORDS + i];
     __syncthreads();
-    for (int o = lane; o < AZB_ORIENTS; o += 64) {
-        int c = 0;
-        for (int wd = 0; wd < AZB_WORDS; ++wd) c += __popc(s_bits[o * AZB_WORDS + wd]);
-        s_cnt[o] = c;
-    }
-    __syncthreads();
+    azb_count(s_bits, s_cnt);
     for (int s = 0; s < steps; ++s) {
         if (s_meta[1]) break;
-        if (lane == 0) {
-            unsigned r[4];
-            az_philox4(d.seed, (unsigned)(d.slot_base + g), (unsigned)s_meta[2], r);
-            const int k = (int)(((unsigned long long)r[0] * (unsigned)s_meta[3]) >> 32);
-            s_pick = azb_kth_action(s_bits, s_cnt, k);
-        }
+        unsigned r[4];
+        az_philox4(d.seed, (unsigned)(d.slot_base + g), (unsigned)s_meta[2], r);
+        const int k = (int)(((unsigned long long)r[0] * (unsigned)s_meta[3]) >> 32);
+        const int pick = azb_kth_action(s_bits, s_cnt, k);
+        if (lane == 0) s_pick = pick;
         __syncthreads();
-        azb_play(d, g, s_pick, s_own, s_forb, s_contact, s_bits, s_cnt, s_used, s_last, s_meta, nullptr, nullptr);
+        azb_play(d, g, s_pick, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta, nullptr, nullptr);
     }
 }
 
@@ -250,7 +277,7 @@ extern "C" __global__ void azb_export_kernel(AzbDev d, uint8_t* planes, uint8_t*
     if (mask)
         for (int a = threadIdx.x; a < AZB_ACTIONS; a += blockDim.x) {
             const int o = a / AZB_CELLS, cell = a % AZB_CELLS;
-            mask[(size_t)g * AZB_ACTIONS + a] = d.legal_bits[(size_t)g * AZB_SET_WORDS + o * AZB_WORDS + (cell >> 5)] >> (cell & 31) & 1u;
+            mask[(size_t)g * AZB_ACTIONS + a] = d.legal_bits[(size_t)g * AZB_SET_WORDS + o * AZB_WORDS + cell / AZB_N] >> (cell % AZB_N) & 1u;
         }
 }
 
