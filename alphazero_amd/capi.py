@@ -29,6 +29,8 @@ EXPORTS = [
     "az_blokus_create", "az_blokus_destroy", "az_blokus_reset", "az_blokus_step", "az_blokus_legal_mask", "az_blokus_boards",
     "az_blokus_state", "az_blokus_playout", "az_blokus_sync", "az_blokus_stream", "az_blokus_orient", "az_blokus_host_state_size",
     "az_blokus_host_reset", "az_blokus_host_step", "az_blokus_host_legal", "az_blokus_host_info",
+    "az_blokus_search_config", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
+    "az_blokus_eval_hash", "az_blokus_eval_io", "az_blokus_search_result", "az_blokus_search_stats",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
@@ -119,6 +121,7 @@ def load():
         L.az_blokus_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int]
         L.az_blokus_host_state_size.restype = C.c_size_t
         L.az_blokus_stream.restype = C.c_void_p
+        L.az_blokus_search_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -409,6 +412,39 @@ class Blokus:
 
     def playout(self, steps):
         _chk(load().az_blokus_playout(self.h, int(steps)))
+
+    # -- MCTS ----------------------------------------------------------------
+    def search_config(self, vl=3.0, c_puct=3.0, max_budget=400, edge_cap=0):
+        _chk(load().az_blokus_search_config(self.h, vl, c_puct, int(max_budget), int(edge_cap)))
+
+    def set_noise(self, noise):
+        if noise is None:
+            _chk(load().az_blokus_set_noise(self.h, None, 0))
+            return
+        noise = np.ascontiguousarray(noise, np.float32)
+        assert noise.shape[0] == self.G
+        _chk(load().az_blokus_set_noise(self.h, _ptr(noise), noise.shape[1]))
+
+    def search(self, budget):
+        _chk(load().az_blokus_search(self.h, int(budget)))
+
+    def search_result(self, game):
+        L = load()
+        nc, rn = C.c_int32(), C.c_int32()
+        _chk(L.az_blokus_search_result(self.h, game, 0, C.byref(nc), C.byref(rn), None, None, None, None))
+        k = nc.value
+        out = dict(actions=np.zeros(k, np.int32), n=np.zeros(k, np.int32), v=np.zeros(k, np.float32), p=np.zeros(k, np.float32))
+        if k:
+            _chk(L.az_blokus_search_result(self.h, game, k, C.byref(nc), C.byref(rn), _ptr(out["actions"]), _ptr(out["n"]),
+                                           _ptr(out["v"]), _ptr(out["p"])))
+        out["root_n"] = rn.value
+        return out
+
+    def search_stats(self):
+        mn, ms, rs = C.c_int32(), C.c_int32(), C.c_int32()
+        rd = C.c_int64()
+        _chk(load().az_blokus_search_stats(self.h, C.byref(mn), C.byref(ms), C.byref(rs), C.byref(rd)))
+        return dict(max_nodes=mn.value, max_slots=ms.value, restarts=rs.value, rounds=rd.value)
 
     def sync(self):
         _chk(load().az_blokus_sync(self.h))

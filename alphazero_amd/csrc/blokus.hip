@@ -44,7 +44,34 @@ struct AzbDev {
     int*      legal_count;  // [G] legal actions of the player to move (0 once over)
     uint32_t* legal_bits;   // [G][91][20] row masks
     float*    final_reward; // [G][4]
+    // ---- search (MCTS) state, allocated by az_blokus_search_config ----
+    float vl; int c_puct_i;
+    int edge_cap;           // arena slots per game
+    int use_noise;
+    AzEdge*   edges;        // [G][edge_cap]  a node = one header slot {n = child count, child = player to move} + its child edges
+    uint16_t* eact;         // [G][edge_cap]  action of each child edge
+    int*      n_slots;      // [G] arena slots in use
+    int*      n_nodes;      // [G] expanded nodes
+    int*      root_n;       // [G]
+    int*      t_status;     // [G] 1 while the search runs
+    int*      sims_done;    // [G]
+    int*      sims_target;  // [G]
+    int*      pending;      // [G] AZ_PEND_*
+    int*      path_len;     // [G]
+    int*      path;         // [G][AZB_PATH_CAP] edge slots root -> leaf
+    uint8_t*  path_owner;   // [G][AZB_PATH_CAP] who chose at each level
+    float*    pend_result;  // [G][4] reward of a terminal leaf
+    uint32_t* leaf_bits;    // [G][91][20] legal set of the leaf awaiting its evaluation
+    int*      leaf_count;   // [G]
+    uint8_t*  leaf_player;  // [G]
+    uint8_t*  leaf_planes;  // [G][5][400] evaluator input
+    float*    policy;       // [G][91*400] evaluator output
+    float*    value;        // [G][4]
+    float*    noise;        // [G][AZB_NOISE_CAP]
+    int*      restarts;     // [G] searches restarted because the arena was full
 };
+#define AZB_PATH_CAP 88                                 // a game has at most 84 pieces
+#define AZB_NOISE_CAP 4096
 
 // ---------------------------------------------------------------------------------------------- device
 // The orientation table in LDS, 8 bytes each: x = piece | h << 8 | n << 16 | cell0 << 24, y = cells 1..4, a cell
@@ -145,6 +172,43 @@ __device__ int azb_kth_action(const uint32_t* s_bits, const int* s_cnt, int k) {
     return o * AZB_CELLS + AZB_N * y + (__ffs((int)v) - 1);
 }
 
+// Player p's piece `action` onto the position in LDS.
+__device__ void azb_place(uint32_t* s_own, uint32_t* s_used, int* s_last, int p, int action) {
+    const int lane = threadIdx.x;
+    const int o = action / AZB_CELLS, y0 = action % AZB_CELLS / AZB_N, x0 = action % AZB_N;
+    __syncthreads();
+    if (lane < c_orient[o].h) s_own[p * AZB_N + y0 + lane] |= (uint32_t)c_orient[o].rows[lane] << x0;
+    if (lane == 0) { s_used[p] |= 1u << c_orient[o].piece; s_last[p] = c_orient[o].piece; }
+    __syncthreads();
+}
+
+// After player p moved: the next player (cyclically) who has a legal action, with that action set in
+// s_bits / s_cnt and its size in *cnt; -1 when nobody can move.
+__device__ int azb_next_player(const uint32_t* s_own, const uint32_t* s_used, int p, uint2* s_rows, const uint2* s_tab,
+                               uint32_t* s_bits, int* s_cnt, int* cnt) {
+    for (int k = 1; k <= AZB_PLAYERS; ++k) {
+        const int q = (p + k) & 3;
+        *cnt = azb_scan(s_own, s_used[q], q, s_rows, s_tab, s_bits, s_cnt);
+        if (*cnt > 0) return q;
+    }
+    *cnt = 0;
+    return -1;
+}
+
+// End of the game: the reward of every player from the hands (every lane computes the same four values).
+__device__ void azb_final_reward_dev(const uint32_t* s_used, const int* s_last, float r[4]) {
+    int score[4], best = -1000;
+    bool all_equal = true;
+    for (int q = 0; q < 4; ++q) {
+        int left = 0;
+        for (int pc = 0; pc < AZB_PIECES; ++pc) if (!(s_used[q] >> pc & 1u)) left += c_piece_size[pc];
+        score[q] = left ? -left : 15 + (s_last[q] == 0 ? 5 : 0);
+        best = max(best, score[q]);
+        all_equal = all_equal && score[q] == score[0];
+    }
+    for (int q = 0; q < 4; ++q) r[q] = all_equal ? 0.f : (score[q] == best ? 1.f : -1.f);
+}
+
 // Places `action` (known legal) for the player to move, then hands the turn to the next player who can move,
 // or ends the game.  s_own / s_used / s_last / s_meta {to_move, over, pieces placed, legal count} hold the
 // game (and stay current, so a kernel can play on without re-reading HBM); the state arrays are updated too.
@@ -152,39 +216,23 @@ __device__ void azb_play(const AzbDev& d, int g, int action, uint32_t* s_own, ui
                          uint32_t* s_bits, int* s_cnt, uint32_t* s_used, int* s_last, int* s_meta, float* reward, uint8_t* done) {
     const int lane = threadIdx.x;
     const int p = s_meta[0];
-    const int o = action / AZB_CELLS, y0 = action % AZB_CELLS / AZB_N, x0 = action % AZB_N;
-    __syncthreads();
-    if (lane < c_orient[o].h) s_own[p * AZB_N + y0 + lane] |= (uint32_t)c_orient[o].rows[lane] << x0;
-    if (lane == 0) { s_used[p] |= 1u << c_orient[o].piece; s_last[p] = c_orient[o].piece; }
-    __syncthreads();
-    int next = -1, cnt = 0;
-    for (int k = 1; k <= AZB_PLAYERS; ++k) {
-        const int q = (p + k) & 3;
-        cnt = azb_scan(s_own, s_used[q], q, s_rows, s_tab, s_bits, s_cnt);
-        if (cnt > 0) { next = q; break; }
-    }
+    azb_place(s_own, s_used, s_last, p, action);
+    int cnt = 0;
+    const int next = azb_next_player(s_own, s_used, p, s_rows, s_tab, s_bits, s_cnt, &cnt);
     // write the position back: only player p's rows and masks changed
     if (lane < AZB_N) d.own[((size_t)g * 4 + p) * AZB_N + lane] = s_own[p * AZB_N + lane];
     for (int i = lane; i < AZB_SET_WORDS; i += 64) d.legal_bits[(size_t)g * AZB_SET_WORDS + i] = next >= 0 ? s_bits[i] : 0u;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (next < 0) azb_final_reward_dev(s_used, s_last, r);
+    __syncthreads();
     if (lane == 0) {
         d.used[g * 4 + p] = s_used[p];
         d.last_piece[g * 4 + p] = (uint8_t)s_last[p];
         s_meta[2] += 1; d.moves[g] = s_meta[2];
-        s_meta[3] = next >= 0 ? cnt : 0; d.legal_count[g] = s_meta[3];
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        s_meta[3] = cnt; d.legal_count[g] = cnt;
         if (next >= 0) { s_meta[0] = next; d.to_move[g] = (uint8_t)next; }
-        else {                                                       // nobody can move: score the hands
+        else {                                                       // nobody can move: the hands are scored
             s_meta[1] = 1; d.over[g] = 1;
-            int score[4], best = -1000;
-            bool all_equal = true;
-            for (int q = 0; q < 4; ++q) {
-                int left = 0;
-                for (int pc = 0; pc < AZB_PIECES; ++pc) if (!(s_used[q] >> pc & 1u)) left += c_piece_size[pc];
-                score[q] = left ? -left : 15 + (s_last[q] == 0 ? 5 : 0);
-                best = max(best, score[q]);
-                all_equal = all_equal && score[q] == score[0];
-            }
-            for (int q = 0; q < 4; ++q) r[q] = all_equal ? 0.f : (score[q] == best ? 1.f : -1.f);
             for (int q = 0; q < 4; ++q) d.final_reward[g * 4 + q] = r[q];
         }
         if (reward) for (int q = 0; q < 4; ++q) reward[g * 4 + q] = r[q];
@@ -281,6 +329,238 @@ extern "C" __global__ void azb_export_kernel(AzbDev d, uint8_t* planes, uint8_t*
         }
 }
 
+// ------------------------------------------------------------------------------------------- search (MCTS)
+// MCTS::search_probs for G Blokus games in lockstep rounds, one tree per wavefront, the reference's arithmetic
+// (node.hpp:47-55 PUCT with int c_puct and a double intermediate; mcts.hpp:225-227 virtual loss; :328-345
+// backup; :425-455 expansion with the raw prior and the 0.75/0.25 Dirichlet mix at a parentless root; :266-269
+// terminal leaves) on what Blokus changes: four players, so an edge is valued for the player who chooses it
+// (value = result[player to move at the parent], the reference's result[parent->player] with four entries),
+// and an irregular action set, so a node carries its own child count: a node is a header slot {n = number of
+// children, child = player to move} followed by its child edges in action order; an edge's link is the slot
+// of its child's header (> 0), -1 a stub, -16 - code a terminal leaf whose reward is packed two bits per
+// player in code.  Every search starts from a fresh root.
+#define AZB_TERMINAL(code_) (-16 - (code_))
+__device__ __forceinline__ int azb_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ int azb_pack_reward(const float r[4]) {
+    int code = 0;
+    for (int q = 0; q < 4; ++q) code |= (r[q] > 0.f ? 1 : (r[q] < 0.f ? 2 : 0)) << (2 * q);
+    return code;
+}
+__device__ void azb_unpack_reward(int code, float r[4]) {
+    for (int q = 0; q < 4; ++q) { const int c = code >> (2 * q) & 3; r[q] = c == 1 ? 1.f : (c == 2 ? -1.f : 0.f); }
+}
+
+__device__ void azb_write_planes(const AzbDev& d, int g, const uint32_t* s_own, int to_move) {
+    uint8_t* pl = d.leaf_planes + (size_t)g * AZB_PLANES * AZB_CELLS;
+    for (int i = threadIdx.x; i < AZB_CELLS; i += 64) {
+        const int y = i / AZB_N, x = i - AZB_N * y;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) pl[p * AZB_CELLS + i] = s_own[p * AZB_N + y] >> x & 1u;
+        pl[4 * AZB_CELLS + i] = (uint8_t)to_move;
+    }
+}
+
+// Consume the evaluation of the previous round: expand (+ noise at the root) and back up.
+__device__ void azb_tree_apply(const AzbDev& d, int g) {
+    const int lane = threadIdx.x;
+    const int pend = azb_uni(d.pending[g]);
+    if (pend == AZ_PEND_NONE) return;
+    AzEdge* E = d.edges + (size_t)g * d.edge_cap;
+    uint16_t* EA = d.eact + (size_t)g * d.edge_cap;
+    const int plen = azb_uni(d.path_len[g]);
+    const int* path = d.path + (size_t)g * AZB_PATH_CAP;
+    if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
+        const int cnt = azb_uni(d.leaf_count[g]);
+        const int hdr = azb_uni(d.n_slots[g]);
+        if (hdr + 1 + cnt > d.edge_cap) {
+            // arena full: drop the tree and search the position again from a fresh root (mcts.hpp:392-414)
+            if (lane == 0) { d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; d.sims_done[g] = 0; d.pending[g] = AZ_PEND_NONE; d.restarts[g] += 1; }
+            __syncthreads();
+            return;
+        }
+        const bool is_root = pend == AZ_PEND_ROOT;
+        const float* pol = d.policy + (size_t)g * AZB_ACTIONS;
+        const float* nz = d.noise + (size_t)g * AZB_NOISE_CAP;
+        const uint32_t* bits = d.leaf_bits + (size_t)g * AZB_SET_WORDS;
+        if (lane == 0) { AzEdge h = {0.f, cnt, 0.f, (int)d.leaf_player[g]}; E[hdr] = h; EA[hdr] = 0; }
+        int base = hdr + 1;
+        for (int c = 0; c < AZB_SET_WORDS; c += 64) {                  // words in (o, y) order = action order
+            const int i = c + lane;
+            uint32_t w = i < AZB_SET_WORDS ? bits[i] : 0u;
+            int x = __popc(w);
+            const int own = x;
+            for (int dd = 1; dd < 64; dd <<= 1) { const int y = __shfl_up(x, dd, 64); if (lane >= dd) x += y; }
+            int k = base + x - own;
+            while (w) {
+                const int bit = __ffs((int)w) - 1;
+                w &= w - 1u;
+                const int action = i * AZB_N + bit;                    // (o*20 + y)*20 + x
+                float prior = pol[action];
+                if (is_root && d.use_noise) {                          // mcts.hpp:445 (double literals)
+                    const int kk = k - (hdr + 1);
+                    prior = (float)(0.75 * (double)prior + 0.25 * (double)(kk < AZB_NOISE_CAP ? nz[kk] : 0.f));
+                }
+                AzEdge e = {prior, 0, 0.f, -1};
+                E[k] = e;
+                EA[k] = (uint16_t)action;
+                ++k;
+            }
+            base += __shfl(x, 63, 64);
+        }
+        if (lane == 0) {
+            d.n_slots[g] = hdr + 1 + cnt;
+            d.n_nodes[g] = d.n_nodes[g] + 1;
+            if (!is_root) E[path[plen - 1]].child = hdr;               // leaf->add (mcts.hpp:316)
+        }
+        __syncthreads();
+    }
+    if (pend == AZ_PEND_ROOT) {
+        if (lane == 0) d.root_n[g] = 1;                                 // mcts.hpp:412-413
+    } else {                                                            // __backup (mcts.hpp:328-345)
+        const float* res = pend == AZ_PEND_TERMINAL ? d.pend_result + 4 * g : d.value + 4 * g;
+        const float vl = d.vl;
+        for (int t = lane; t < plen; t += 64) {
+            AzEdge* e = &E[path[t]];
+            const float value = res[d.path_owner[(size_t)g * AZB_PATH_CAP + t]];     // result[parent->player]
+            e->n = (int)((float)e->n + (1.f - vl));
+            e->v = e->v + (value + vl);
+        }
+        if (lane == 0) { d.root_n[g] = d.root_n[g] + 1; d.sims_done[g] = d.sims_done[g] + 1; }
+    }
+    if (lane == 0) d.pending[g] = AZ_PEND_NONE;
+    __syncthreads();
+}
+
+// One descent (__select_and_eval + _eval's env step, mcts.hpp:211-321).  s_* hold the root position on entry.
+__device__ void azb_tree_select(const AzbDev& d, int g, uint32_t* s_own, uint2* s_rows, const uint2* s_tab,
+                                uint32_t* s_bits, int* s_cnt, uint32_t* s_used, int* s_last, int* s_meta) {
+    const int lane = threadIdx.x;
+    AzEdge* E = d.edges + (size_t)g * d.edge_cap;
+    const uint16_t* EA = d.eact + (size_t)g * d.edge_cap;
+    int* path = d.path + (size_t)g * AZB_PATH_CAP;
+    uint8_t* owners = d.path_owner + (size_t)g * AZB_PATH_CAP;
+    if (azb_uni(d.n_nodes[g]) == 0) {                                   // fresh root: evaluate the root position
+        for (int i = lane; i < AZB_SET_WORDS; i += 64) d.leaf_bits[(size_t)g * AZB_SET_WORDS + i] = d.legal_bits[(size_t)g * AZB_SET_WORDS + i];
+        azb_write_planes(d, g, s_own, s_meta[0]);
+        if (lane == 0) { d.leaf_count[g] = s_meta[3]; d.leaf_player[g] = (uint8_t)s_meta[0]; d.pending[g] = AZ_PEND_ROOT; d.path_len[g] = 0; }
+        return;
+    }
+    const float vl = d.vl;
+    const float cpf = (float)d.c_puct_i;
+    int hdr = 0, par_n = azb_uni(d.root_n[g]), depth = 0, pend = AZ_PEND_NONE;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        const AzEdge h = E[hdr];
+        const int cnt = azb_uni(h.n), owner = azb_uni(h.child);
+        const double sq = sqrt((double)(par_n - 1));                    // node.hpp:54
+        float best_val = -100.f;                                        // mcts.hpp:355
+        int best_k = -1;
+        for (int k = lane; k < cnt; k += 64) {
+            const AzEdge e = E[hdr + 1 + k];
+            const float cp = cpf * e.p;
+            const float q = e.n != 0 ? __fdiv_rn(e.v, (float)e.n) : 0.f;
+            const float val = (float)((double)q + (double)cp * sq / (double)(1 + e.n));
+            if (val > best_val) { best_val = val; best_k = k; }
+        }
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {                           // first maximum in child order
+            const float ov = __shfl_xor(best_val, o2, 64);
+            const int ok = __shfl_xor(best_k, o2, 64);
+            if (ok >= 0 && (best_k < 0 || ov > best_val || (ov == best_val && ok < best_k))) { best_val = ov; best_k = ok; }
+        }
+        const int ei = hdr + 1 + azb_uni(best_k);
+        AzEdge e = E[ei];
+        const int action = EA[ei];
+        e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227
+        e.v = e.v - vl;
+        if (lane == 0) { E[ei].n = e.n; E[ei].v = e.v; path[depth] = ei; owners[depth] = (uint8_t)owner; }
+        azb_place(s_own, s_used, s_last, owner, action);
+        ++depth;
+        const int child = azb_uni(e.child);
+        if (child > 0) { hdr = child; par_n = azb_uni(e.n); continue; }
+        if (child <= -16) {                                             // stored terminal reward (mcts.hpp:232-233)
+            azb_unpack_reward(-16 - child, res);
+            pend = AZ_PEND_TERMINAL;
+            break;
+        }
+        // stub: Env::step on the parent's state (mcts.hpp:261)
+        int cnt2 = 0;
+        const int next = azb_next_player(s_own, s_used, owner, s_rows, s_tab, s_bits, s_cnt, &cnt2);
+        if (next < 0) {                                                 // terminal_add (mcts.hpp:266-269)
+            azb_final_reward_dev(s_used, s_last, res);
+            if (lane == 0) E[ei].child = AZB_TERMINAL(azb_pack_reward(res));
+            pend = AZ_PEND_TERMINAL;
+        } else {
+            for (int i = lane; i < AZB_SET_WORDS; i += 64) d.leaf_bits[(size_t)g * AZB_SET_WORDS + i] = s_bits[i];
+            azb_write_planes(d, g, s_own, next);
+            if (lane == 0) { d.leaf_count[g] = cnt2; d.leaf_player[g] = (uint8_t)next; }
+            pend = AZ_PEND_LEAF;
+        }
+        break;
+    }
+    if (lane == 0) {
+        d.pending[g] = pend;
+        d.path_len[g] = depth;
+        if (pend == AZ_PEND_TERMINAL) for (int q = 0; q < 4; ++q) d.pend_result[4 * g + q] = res[q];
+    }
+    __syncthreads();
+}
+
+// One lockstep round: apply the pending evaluation, then (unless the search is complete) select the next leaf.
+extern "C" __global__ void __launch_bounds__(64) azb_round_kernel(AzbDev d) {
+    AZB_SMEM_DECL;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (azb_uni(d.t_status[g]) != AZ_ST_RUN) return;
+    azb_tree_apply(d, g);
+    if (azb_uni(d.sims_done[g]) >= azb_uni(d.sims_target[g])) {
+        if (lane == 0) d.t_status[g] = AZ_ST_IDLE;
+        return;
+    }
+    azb_load_table(s_tab);
+    azb_load(d, g, s_own, s_used, s_last, s_meta);
+    azb_tree_select(d, g, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta);
+}
+
+extern "C" __global__ void azb_search_begin_kernel(AzbDev d, int budget) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0;
+    d.sims_done[g] = 0; d.sims_target[g] = budget > 1 ? budget : 1;     // the loop body runs once even for budget <= 0
+    d.pending[g] = AZ_PEND_NONE; d.path_len[g] = 0;
+    d.t_status[g] = d.over[g] ? AZ_ST_IDLE : AZ_ST_RUN;
+}
+
+// Integer-hash pseudo network (parity evaluator): planes u8 [5*400] -> policy f32 [36400], value f32 [4].
+extern "C" __global__ void __launch_bounds__(256) azb_eval_hash_kernel(const uint8_t* planes, float* policy, float* value) {
+    __shared__ unsigned long long s_h[4];
+    __shared__ unsigned s_sum[4];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t* pl = planes + (size_t)g * AZB_PLANES * AZB_CELLS;
+    unsigned long long H = 0;
+    for (int i = tid; i < AZB_PLANES * AZB_CELLS; i += 256) H ^= az_splitmix64((unsigned long long)i * 256ull + pl[i]);
+    for (int o = 32; o > 0; o >>= 1) H ^= __shfl_xor(H, o, 64);
+    if (lane == 0) s_h[wv] = H;
+    __syncthreads();
+    H = s_h[0] ^ s_h[1] ^ s_h[2] ^ s_h[3];
+    unsigned sum = 0;
+    for (int i = tid; i < AZB_ACTIONS; i += 256) {
+        const unsigned long long r = (az_splitmix64(H + (unsigned long long)i + 1ull) >> 40) & 0xFFFFull;
+        sum += 1u + (unsigned)((r * r * r) >> 32);
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) s_sum[wv] = sum;
+    __syncthreads();
+    const float fs = (float)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+    for (int i = tid; i < AZB_ACTIONS; i += 256) {
+        const unsigned long long r = (az_splitmix64(H + (unsigned long long)i + 1ull) >> 40) & 0xFFFFull;
+        policy[(size_t)g * AZB_ACTIONS + i] = __fdiv_rn((float)(1u + (unsigned)((r * r * r) >> 32)), fs);
+    }
+    if (tid < 4) {
+        const int t = (int)((az_splitmix64(H ^ (0xABCDEFull + (unsigned long long)tid)) >> 40) & 0xFFFFull);
+        value[4 * g + tid] = __fdiv_rn((float)t - 32768.0f, 40000.0f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct az_blokus {
     int device = 0;
@@ -289,12 +569,15 @@ struct az_blokus {
     std::vector<void*> allocs;
     int* d_actions = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; int* d_illegal = nullptr;
     uint8_t* d_export = nullptr;      // [G][91*400] mask or [G][5][400] planes
+    int max_budget = 0;
+    int64_t rounds = 0;
 };
 
 static int bfail(int code, const std::string& m) { return az_internal_fail(code, m.c_str()); }
 #define BHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
     return bfail(AZ_E_HIP, std::string(#call " failed: ") + hipGetErrorString(e_)); } while (0)
 #define BNEED(p) do { if (!(p)) return bfail(AZ_E_ARG, "null argument: " #p); } while (0)
+#define AZB_CHK(call) do { int r_ = (call); if (r_ != AZ_OK) return r_; } while (0)
 
 static const AzbOrient* host_table() {
     static AzbOrient T[AZB_ORIENTS + 8];
@@ -352,6 +635,7 @@ extern "C" int az_blokus_create(az_blokus** out, int device, int G, uint64_t see
     BA(b->d_export, (size_t)G * AZB_ACTIONS);
 #undef BA
     if (rc == AZ_OK && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) rc = bfail(AZ_E_HIP, "hipStreamCreate failed");
+    if (rc == AZ_OK && hipDeviceSynchronize() != hipSuccess) rc = bfail(AZ_E_HIP, "hipDeviceSynchronize failed");   // zero fills (null stream) before the context's stream is used
     if (rc != AZ_OK) { const std::string keep = az_last_error(); az_blokus_destroy(b); return bfail(rc, keep); }
     *out = b;
     return az_blokus_reset(b);
@@ -425,6 +709,164 @@ extern "C" int az_blokus_state(az_blokus* b, uint8_t* to_move, uint8_t* over, in
     if (used) BHIP(hipMemcpyAsync(used, b->d.used, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, b->stream));
     if (final_reward) BHIP(hipMemcpyAsync(final_reward, b->d.final_reward, sizeof(float) * 4 * G, hipMemcpyDeviceToHost, b->stream));
     BHIP(hipStreamSynchronize(b->stream));
+    return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------ search, host side
+// MCTS(nthreads = 1, batch, vl, c_puct) for the Blokus games (mcts.hpp:41-73): allocates the trees.
+extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int max_budget, int edge_cap) {
+    BNEED(b);
+    if (b->d.edges) return bfail(AZ_E_STATE, "the search is already configured");
+    if (max_budget < 1) return bfail(AZ_E_ARG, "max_budget must be >= 1");
+    BHIP(hipSetDevice(b->device));
+    const int G = b->d.G;
+    b->d.vl = vl; b->d.c_puct_i = (int)c_puct;                        // Node::ucb takes int (node.hpp:47)
+    b->d.edge_cap = edge_cap > 0 ? edge_cap : (max_budget + 2) * 768;   // ~510 slots per node observed at 2048 games x 400 sims
+    b->max_budget = max_budget;
+    int rc = AZ_OK;
+#define BA(ptr, n) do { if (rc == AZ_OK) rc = balloc(b, &(ptr), (size_t)(n)); } while (0)
+    BA(b->d.edges, (size_t)G * b->d.edge_cap); BA(b->d.eact, (size_t)G * b->d.edge_cap);
+    BA(b->d.n_slots, G); BA(b->d.n_nodes, G); BA(b->d.root_n, G); BA(b->d.t_status, G); BA(b->d.sims_done, G); BA(b->d.sims_target, G);
+    BA(b->d.pending, G); BA(b->d.path_len, G); BA(b->d.path, (size_t)G * AZB_PATH_CAP); BA(b->d.path_owner, (size_t)G * AZB_PATH_CAP);
+    BA(b->d.pend_result, (size_t)G * 4); BA(b->d.leaf_bits, (size_t)G * AZB_SET_WORDS); BA(b->d.leaf_count, G); BA(b->d.leaf_player, G);
+    BA(b->d.leaf_planes, (size_t)G * AZB_PLANES * AZB_CELLS); BA(b->d.policy, (size_t)G * AZB_ACTIONS); BA(b->d.value, (size_t)G * 4);
+    BA(b->d.noise, (size_t)G * AZB_NOISE_CAP); BA(b->d.restarts, G);
+#undef BA
+    if (rc != AZ_OK) { b->d.edges = nullptr; return rc; }
+    BHIP(hipDeviceSynchronize());            // the zero fills ran on the null stream, the context's stream does not wait for it
+    return AZ_OK;
+}
+
+// util.h:42-58 made an input: noise f32 [G][n] (n <= 4096), entry k for the k-th legal action of a fresh root
+extern "C" int az_blokus_set_noise(az_blokus* b, const float* noise, int n) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipStreamSynchronize(b->stream));
+    if (!noise) { b->d.use_noise = 0; return AZ_OK; }
+    if (n < 1 || n > AZB_NOISE_CAP) return bfail(AZ_E_ARG, "noise length out of range (1..4096)");
+    BHIP(hipMemcpy2D(b->d.noise, sizeof(float) * AZB_NOISE_CAP, noise, sizeof(float) * n, sizeof(float) * n, b->d.G, hipMemcpyHostToDevice));
+    b->d.use_noise = 1;
+    return AZ_OK;
+}
+
+// The evaluator's device buffers, for an evaluator outside the library: planes u8 [G,5,20,20] in,
+// policy f32 [G,91*400] and value f32 [G,4] out (the Evaluator's role, evaluator.hpp:80-124).
+extern "C" int az_blokus_eval_io(az_blokus* b, uint8_t** planes_dev, float** policy_dev, float** value_dev) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    if (planes_dev) *planes_dev = b->d.leaf_planes;
+    if (policy_dev) *policy_dev = b->d.policy;
+    if (value_dev) *value_dev = b->d.value;
+    return AZ_OK;
+}
+
+extern "C" int az_blokus_search_begin(az_blokus* b, int budget) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    if (budget > b->max_budget) return bfail(AZ_E_ARG, "budget exceeds the max_budget given to az_blokus_search_config");
+    BHIP(hipSetDevice(b->device));
+    hipLaunchKernelGGL(azb_search_begin_kernel, dim3((b->d.G + 63) / 64), dim3(64), 0, b->stream, b->d, budget);
+    BHIP(hipGetLastError());
+    return AZ_OK;
+}
+
+// One lockstep round of the search: apply the evaluations in the evaluator's buffers, select the next leaves
+// (their planes go to the evaluator's input).  *n_running = games whose search is not finished yet (or NULL:
+// no synchronisation).
+extern "C" int az_blokus_search_round(az_blokus* b, int* n_running) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    hipLaunchKernelGGL(azb_round_kernel, dim3(b->d.G), dim3(64), 0, b->stream, b->d);
+    BHIP(hipGetLastError());
+    b->rounds++;
+    if (n_running) {
+        std::vector<int> st((size_t)b->d.G);
+        BHIP(hipMemcpyAsync(st.data(), b->d.t_status, sizeof(int) * b->d.G, hipMemcpyDeviceToHost, b->stream));
+        BHIP(hipStreamSynchronize(b->stream));
+        int run = 0;
+        for (int x : st) run += x == AZ_ST_RUN;
+        *n_running = run;
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_blokus_eval_hash(az_blokus* b) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    hipLaunchKernelGGL(azb_eval_hash_kernel, dim3(b->d.G), dim3(256), 0, b->stream, b->d.leaf_planes, b->d.policy, b->d.value);
+    BHIP(hipGetLastError());
+    return AZ_OK;
+}
+
+// MCTS::search_probs (mcts.hpp:105-155) for all G games with the integer-hash evaluator: `budget` simulations
+// per game from a fresh root.
+extern "C" int az_blokus_search(az_blokus* b, int budget) {
+    AZB_CHK(az_blokus_search_begin(b, budget));
+    const int bb = budget > 1 ? budget : 1;
+    for (int r = 0; r < bb + 2; ++r) {
+        AZB_CHK(az_blokus_search_round(b, nullptr));
+        if (r < bb + 1) AZB_CHK(az_blokus_eval_hash(b));
+    }
+    for (int extra = 0;; ++extra) {                                  // restarts (a full arena) need more rounds
+        int run = 0;
+        AZB_CHK(az_blokus_eval_hash(b));
+        AZB_CHK(az_blokus_search_round(b, &run));
+        if (!run) break;
+        if (extra > 4 * (bb + 2)) return bfail(AZ_E_STATE, "search did not finish within its round bound");
+    }
+    return AZ_OK;
+}
+
+// The root of game g after a search: its children in action order.  cap = 0 sizes (*n_children, *root_n).
+extern "C" int az_blokus_search_result(az_blokus* b, int game, int cap, int32_t* n_children, int32_t* root_n,
+                                       int32_t* actions, int32_t* n, float* v, float* p) {
+    BNEED(b); BNEED(n_children);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    if (game < 0 || game >= b->d.G) return bfail(AZ_E_ARG, "game out of range");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipStreamSynchronize(b->stream));
+    int nn = 0, rn = 0, st = 0;
+    BHIP(hipMemcpy(&nn, b->d.n_nodes + game, 4, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(&rn, b->d.root_n + game, 4, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(&st, b->d.t_status + game, 4, hipMemcpyDeviceToHost));
+    if (st == AZ_ST_RUN) return bfail(AZ_E_STATE, "the search of this game has not finished");
+    AzEdge hdr = {0.f, 0, 0.f, 0};
+    if (nn > 0) BHIP(hipMemcpy(&hdr, b->d.edges + (size_t)game * b->d.edge_cap, sizeof hdr, hipMemcpyDeviceToHost));
+    *n_children = nn > 0 ? hdr.n : 0;
+    if (root_n) *root_n = rn;
+    if (cap == 0) return AZ_OK;
+    if (cap < *n_children) return bfail(AZ_E_ARG, "result buffers too small");
+    BNEED(actions); BNEED(n); BNEED(v); BNEED(p);
+    std::vector<AzEdge> ed((size_t)*n_children);
+    std::vector<uint16_t> ea((size_t)*n_children);
+    if (*n_children) {
+        BHIP(hipMemcpy(ed.data(), b->d.edges + (size_t)game * b->d.edge_cap + 1, sizeof(AzEdge) * ed.size(), hipMemcpyDeviceToHost));
+        BHIP(hipMemcpy(ea.data(), b->d.eact + (size_t)game * b->d.edge_cap + 1, 2 * ea.size(), hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < ed.size(); ++i) { actions[i] = ea[i]; n[i] = ed[i].n; v[i] = ed[i].v; p[i] = ed[i].p; }
+    return AZ_OK;
+}
+
+// tallies of the search: expanded nodes and arena slots of the largest tree, restarts, rounds
+extern "C" int az_blokus_search_stats(az_blokus* b, int32_t* max_nodes, int32_t* max_slots, int32_t* restarts, int64_t* rounds) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipStreamSynchronize(b->stream));
+    const int G = b->d.G;
+    std::vector<int> a((size_t)G), s((size_t)G), r((size_t)G);
+    BHIP(hipMemcpy(a.data(), b->d.n_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(s.data(), b->d.n_slots, sizeof(int) * G, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(r.data(), b->d.restarts, sizeof(int) * G, hipMemcpyDeviceToHost));
+    int mn = 0, ms = 0, rs = 0;
+    for (int g = 0; g < G; ++g) { mn = a[g] > mn ? a[g] : mn; ms = s[g] > ms ? s[g] : ms; rs += r[g]; }
+    if (max_nodes) *max_nodes = mn;
+    if (max_slots) *max_slots = ms;
+    if (restarts) *restarts = rs;
+    if (rounds) *rounds = b->rounds;
     return AZ_OK;
 }
 

@@ -238,6 +238,26 @@ int az_blokus_state(az_blokus*, uint8_t* to_move, uint8_t* over, int32_t* moves,
 int az_blokus_playout(az_blokus*, int steps);
 int az_blokus_sync(az_blokus*);
 void* az_blokus_stream(az_blokus*);
+/* MCTS over the Blokus games (MCTS::MCTS + search_probs, mcts.hpp:41-73,105-155, at nthreads = 1): the
+ * reference's search arithmetic on four players and an irregular action set -- an edge is valued for the
+ * player who chooses it (result[parent->player], mcts.hpp:336, with four entries), a node carries its own
+ * child count, children are in action order, ties go to the first child.  Every search starts from a fresh
+ * root; a tree that outgrows its arena (edge_cap slots per game, 0 = (max_budget + 2) * 768) is dropped and
+ * searched again.  az_blokus_search runs `budget` simulations per game with the integer-hash evaluator
+ * (bit-reproducible on the CPU); begin / round / eval_io let an evaluator outside the library take the hash
+ * evaluator's place: after a round its input planes are in *planes_dev, before the next round its outputs
+ * must be in *policy_dev / *value_dev (softmax over all 91*400 actions, value per player). */
+int az_blokus_search_config(az_blokus*, float vl, float c_puct, int max_budget, int edge_cap);
+int az_blokus_set_noise(az_blokus*, const float* noise /* [G,n] or NULL = no noise */, int n);
+int az_blokus_search(az_blokus*, int budget);
+int az_blokus_search_begin(az_blokus*, int budget);
+int az_blokus_search_round(az_blokus*, int* n_running /* or NULL */);
+int az_blokus_eval_hash(az_blokus*);
+int az_blokus_eval_io(az_blokus*, uint8_t** planes_dev, float** policy_dev, float** value_dev);
+/* root children of game g in action order: actions, n, v, p; cap 0 = size only */
+int az_blokus_search_result(az_blokus*, int game, int cap, int32_t* n_children, int32_t* root_n,
+                            int32_t* actions, int32_t* n, float* v, float* p);
+int az_blokus_search_stats(az_blokus*, int32_t* max_nodes, int32_t* max_slots, int32_t* restarts, int64_t* rounds);
 /* the orientation table: piece, bounding box, cells (row, column) row-major; returns the number of cells */
 int az_blokus_orient(int o, int* piece, int* h, int* w, int8_t* cells_yx /* [5][2] */);
 /* the same rules on the host, one game in caller memory of az_blokus_host_state_size() bytes (C++ Env shim,

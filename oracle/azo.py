@@ -316,3 +316,16 @@ class Blokus:
         if getattr(self, "h", None):
             lib().azo_blokus_free(self.h)
             self.h = None
+
+
+def blokus_search(game, budget, noise=None, vl=3.0, c_puct=3.0):
+    """MCTS of the oracle from the game's current position (fresh root): dict of the root's children."""
+    _, k = game.legal()
+    out = dict(actions=np.zeros(k, np.int32), n=np.zeros(k, np.int32), v=np.zeros(k, np.float32), p=np.zeros(k, np.float32))
+    rn, nodes = C.c_int32(), C.c_int64()
+    nz = None if noise is None else _p(np.ascontiguousarray(noise, np.float32), C.c_float)
+    got = lib().azo_blokus_search(game.h, int(budget), C.c_float(vl), C.c_float(c_puct), nz, _p(out["actions"], C.c_int32),
+                                  _p(out["n"], C.c_int32), _p(out["v"], C.c_float), _p(out["p"], C.c_float), C.byref(rn), C.byref(nodes))
+    assert got == k
+    out["root_n"], out["nodes"] = rn.value, nodes.value
+    return out

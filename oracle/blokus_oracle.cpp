@@ -10,6 +10,7 @@
  * Interface contract followed: the Env call sites, mcts.hpp:251-271,427; generate.cpp:75,103.
  */
 #include <algorithm>
+#include <cmath>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -227,6 +228,170 @@ int azo_blokus_random_move(void* h, uint64_t seed, uint32_t stream, uint32_t cou
     const int a = acts[(size_t)(((uint64_t)u * acts.size()) >> 32)];
     *done = step(g, a, reward);
     return a;
+}
+
+}  /* extern "C" */
+
+/* ------------------------------------------------------------------------------------------------------
+ * MCTS over Blokus: the reference's search (mcts.hpp:105-155,211-237,240-346,350-381,425-455; node.hpp:47-55)
+ * stated for an Env with four players and an irregular action set.  What carries over unchanged: the PUCT
+ * score with the int-truncated c_puct and the double intermediate (node.hpp:47-54), virtual loss on the way
+ * down and its repayment in the backup (mcts.hpp:225-227,337-343), expansion of every legal action with the
+ * raw softmax prior, Dirichlet mix 0.75/0.25 at a parentless root in child order (mcts.hpp:432-446), terminal
+ * leaves storing the env reward (mcts.hpp:266-269), exactly `budget` simulations, output = child n / root n.
+ * What the reference leaves to Env and this states: value = result[player to move at the parent] with a
+ * four-entry result (mcts.hpp:336 indexes a two-entry one), children in action-index order, ties to the first
+ * child (the rule the m,n,k search uses too).  Each search starts from a fresh root (no tree reuse yet).
+ * PARITY UNPINNED like the environment itself: the reference cannot run this game. */
+namespace {
+
+uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+const int NA = 91 * 400;
+
+/* integer-hash pseudo network over the u8 [5,20,20] planes: policy f32 [36400] summing to 1, value f32 [4] */
+void eval_hash(const uint8_t* planes, float* policy, float* value) {
+    uint64_t H = 0;
+    for (int i = 0; i < 5 * 400; ++i) H ^= mix64((uint64_t)i * 256u + planes[i]);
+    uint32_t sum = 0;
+    for (int i = 0; i < NA; ++i) {
+        const uint64_t r = (mix64(H + (uint64_t)i + 1u) >> 40) & 0xFFFFu;
+        sum += 1u + (uint32_t)((r * r * r) >> 32);
+    }
+    const float fs = (float)sum;
+    for (int i = 0; i < NA; ++i) {
+        const uint64_t r = (mix64(H + (uint64_t)i + 1u) >> 40) & 0xFFFFu;
+        policy[i] = (float)(1u + (uint32_t)((r * r * r) >> 32)) / fs;
+    }
+    for (int p = 0; p < NP; ++p) {
+        const int t = (int)((mix64(H ^ (0xABCDEFull + (uint64_t)p)) >> 40) & 0xFFFFu);
+        value[p] = ((float)t - 32768.0f) / 40000.0f;
+    }
+}
+
+struct TNode {
+    float p = 0.f; int n = 0; float v = 0.f;
+    int action = -1;
+    int player = 0;                 /* to move here (chooses among the children) */
+    bool expanded = false, terminal = false;
+    float reward[NP] = {0, 0, 0, 0};
+    std::vector<TNode*> kids;       /* in action-index order */
+    ~TNode() { for (TNode* k : kids) delete k; }
+};
+
+struct Search {
+    Game root_state;
+    TNode* root = nullptr;
+    int root_n = 0;
+    float vl = 3.f; int c_puct_i = 3;
+    long evals = 0;
+    ~Search() { delete root; }
+};
+
+void planes_of(const Game& g, uint8_t* planes) {
+    for (int y = 0; y < N; ++y)
+        for (int x = 0; x < N; ++x) {
+            for (int p = 0; p < NP; ++p) planes[p * N * N + y * N + x] = g.board[y][x] == p;
+            planes[NP * N * N + y * N + x] = (uint8_t)g.to_move;
+        }
+}
+
+void expand(Search& s, TNode* node, const Game& g, const float* noise, float* value_out) {
+    static thread_local std::vector<float> policy(NA);
+    uint8_t planes[5 * 400];
+    planes_of(g, planes);
+    eval_hash(planes, policy.data(), value_out);
+    s.evals++;
+    node->player = g.to_move;
+    node->expanded = true;
+    const std::vector<int> acts = legal_actions(g, g.to_move);
+    int k = 0;
+    for (int a : acts) {
+        TNode* c = new TNode;
+        c->action = a;
+        float prior = policy[(size_t)a];
+        if (noise) prior = (float)(0.75 * (double)prior + 0.25 * (double)noise[k]);      /* mcts.hpp:445 */
+        c->p = prior;
+        node->kids.push_back(c);
+        ++k;
+    }
+}
+
+void simulate(Search& s) {
+    TNode* node = s.root;
+    int par_n = s.root_n;
+    std::vector<std::pair<TNode*, int>> path;          /* (child, player to move at its parent) */
+    std::vector<int> actions;
+    float result[NP] = {0, 0, 0, 0};
+    for (;;) {
+        const double sq = std::sqrt((double)(par_n - 1));                                  /* node.hpp:54 */
+        float best = -100.f;                                                               /* mcts.hpp:355 */
+        TNode* pick = nullptr;
+        for (TNode* c : node->kids) {
+            const float cp = (float)s.c_puct_i * c->p;
+            const float q = c->n != 0 ? c->v / (float)c->n : 0.f;
+            const float val = (float)((double)q + (double)cp * sq / (double)(1 + c->n));
+            if (val > best) { best = val; pick = c; }
+        }
+        path.push_back({pick, node->player});
+        actions.push_back(pick->action);
+        pick->n = (int)((float)pick->n + s.vl);                                            /* mcts.hpp:225-227 */
+        pick->v = pick->v - s.vl;
+        if (pick->terminal) { for (int p = 0; p < NP; ++p) result[p] = pick->reward[p]; break; }
+        if (!pick->expanded) {
+            Game g = s.root_state;
+            float rew[NP];
+            int done = 0;
+            for (int a : actions) done = step(g, a, rew);
+            if (done == 1) {                                                               /* mcts.hpp:266-269 */
+                pick->terminal = true;
+                for (int p = 0; p < NP; ++p) { pick->reward[p] = rew[p]; result[p] = rew[p]; }
+            } else expand(s, pick, g, nullptr, result);
+            break;
+        }
+        node = pick;
+        par_n = pick->n;
+    }
+    for (auto& pr : path) {                                                                /* mcts.hpp:328-345 */
+        TNode* c = pr.first;
+        c->n = (int)((float)c->n + (1.f - s.vl));
+        c->v = c->v + (result[pr.second] + s.vl);
+    }
+    s.root_n++;
+}
+
+}  // namespace
+
+extern "C" {
+
+void azo_blokus_eval_hash(const uint8_t* planes, float* policy, float* value) { eval_hash(planes, policy, value); }
+
+/* search_probs from the game's current position: fresh root, `budget` simulations (at least one).
+ * noise f32 [n_legal] or null.  Outputs for the root's children, in action order: actions, n, v, p (each sized
+ * by the caller to the legal count, see azo_blokus_legal); returns the number of children; *root_n out. */
+int azo_blokus_search(void* h, int budget, float vl, float c_puct, const float* noise,
+                      int32_t* actions, int32_t* n, float* v, float* p, int32_t* root_n, int64_t* n_nodes) {
+    Game& g = *(Game*)h;
+    if (g.over) return -1;
+    Search s;
+    s.root_state = g;
+    s.vl = vl; s.c_puct_i = (int)c_puct;
+    s.root = new TNode;
+    float value[NP];
+    expand(s, s.root, g, noise, value);
+    s.root_n = 1;                                                                          /* mcts.hpp:412-413 */
+    const int b = budget > 1 ? budget : 1;
+    for (int i = 0; i < b; ++i) simulate(s);
+    int k = 0;
+    for (TNode* c : s.root->kids) { actions[k] = c->action; n[k] = c->n; v[k] = c->v; p[k] = c->p; ++k; }
+    *root_n = s.root_n;
+    if (n_nodes) *n_nodes = s.evals;
+    return k;
 }
 
 }  /* extern "C" */

@@ -117,3 +117,77 @@ def test_device_playouts_match_the_oracle_at_config_size():
         assert mv == st["moves"][g]
         assert np.array_equal(ref.planes()[:4], planes[g, :4]) and np.array_equal(ref.used(), st["used"][g])
         assert np.array_equal(rew, fr[g])
+
+
+def test_search_matches_the_oracle_bit_for_bit():
+    """MCTS over Blokus (four players, irregular action sets, skipped players and terminal leaves inside the
+    tree) with the integer-hash evaluator and explicit Dirichlet noise: root visit counts, values and priors of
+    every game identical to the oracle's search from the same position.  Positions: the opening, the middle
+    game, and late positions where players are skipped and games end inside the search."""
+    G, budget, seed = 8, 40, 5
+    depth = [0, 1, 7, 20, 41, 52, 58, 60]                  # pieces already on the board, per game
+    dev = capi.Blokus(G, seed=seed)
+    dev.search_config(vl=3.0, c_puct=3.0, max_budget=budget)
+    ref = [azo.Blokus() for _ in range(G)]
+    for g in range(G):                                     # the same random lines on both sides
+        for mv in range(depth[g]):
+            if ref[g].over:
+                break
+            a, _, _ = ref[g].random_move(seed, g, mv)
+            acts = np.full(G, -1, np.int32)
+            acts[g] = a
+            dev.step(acts)
+    _, count = dev.legal_mask(want_mask=False)
+    noise = np.zeros((G, int(count.max())), np.float32)
+    for g in range(G):
+        if count[g]:
+            noise[g, :count[g]] = azo.dirichlet(300 + g, int(count[g]))[0]
+    dev.set_noise(noise)
+    dev.search(budget)
+    st = dev.search_stats()
+    assert st["restarts"] == 0 and st["max_nodes"] <= budget + 1
+    live = 0
+    for g in range(G):
+        got = dev.search_result(g)
+        if ref[g].over:
+            assert len(got["actions"]) == 0
+            continue
+        live += 1
+        want = azo.blokus_search(ref[g], budget, noise[g, :count[g]])
+        assert got["root_n"] == want["root_n"] == budget + 1
+        for k in ("actions", "n", "v", "p"):
+            assert np.array_equal(got[k], want[k]), (g, k)
+        assert got["n"].sum() == budget
+    assert live >= 6
+    # a second search from the same positions starts from a fresh root: same answer
+    dev.search(budget)
+    for g in (0, 3):
+        again = dev.search_result(g)
+        want = azo.blokus_search(ref[g], budget, noise[g, :count[g]])
+        assert np.array_equal(again["n"], want["n"]) and np.array_equal(again["v"], want["v"])
+
+
+def test_search_at_config_size_2048_games_400_sims():
+    """BASELINE configs[3]: 2048 concurrent games x 400 simulations (hash evaluator): every game's root holds
+    exactly 400 visits spread over its legal actions, no tree outgrew its arena; a sample against the oracle."""
+    G, budget = 2048, 400
+    dev = capi.Blokus(G, seed=77)
+    dev.search_config(max_budget=budget)
+    dev.playout(9)                                         # nine random pieces: past the openings
+    dev.sync()
+    _, count = dev.legal_mask(want_mask=False)
+    dev.search(budget)
+    st = dev.search_stats()
+    print("blokus 2048 x 400:", st, "legal actions per root: mean %.0f max %d" % (count.mean(), count.max()))
+    assert st["restarts"] == 0 and st["max_nodes"] <= budget + 1
+    for g in range(0, G, 97):
+        r = dev.search_result(g)
+        assert r["root_n"] == budget + 1 and r["n"].sum() == budget and len(r["actions"]) == count[g]
+        assert (np.diff(r["actions"]) > 0).all() and (r["n"] >= 0).all()
+    ref = azo.Blokus()
+    for mv in range(9):
+        ref.random_move(77, 5, mv)
+    want = azo.blokus_search(ref, budget)
+    got = dev.search_result(5)
+    for k in ("actions", "n", "v", "p"):
+        assert np.array_equal(got[k], want[k]), k
