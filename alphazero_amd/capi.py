@@ -31,6 +31,7 @@ EXPORTS = [
     "az_blokus_host_reset", "az_blokus_host_step", "az_blokus_host_legal", "az_blokus_host_info",
     "az_blokus_search_config", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
     "az_blokus_eval_hash", "az_blokus_eval_io", "az_blokus_search_result", "az_blokus_search_stats",
+    "az_blokus_search_tower", "az_tower_shape",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
@@ -47,6 +48,7 @@ class AzConfig(C.Structure):
         ("Cs", C.c_int * AZ_MAX_LAYERS), ("vl", C.c_float), ("c_puct", C.c_float), ("node_cap", C.c_int),
         ("max_budget", C.c_int), ("eval_mode", C.c_int), ("noise_mode", C.c_int), ("precision", C.c_int),
         ("seed", C.c_uint64), ("game_slot_base", C.c_int), ("leaves_per_round", C.c_int),
+        ("c_in", C.c_int), ("c_out", C.c_int), ("value_dim", C.c_int),
     ]
 
 
@@ -142,7 +144,7 @@ class Engine:
 
     def __init__(self, N, K, G, Cs=None, vl=3.0, c_puct=3.0, max_budget=800, node_cap=0,
                  eval_mode=AZ_EVAL_TOWER, noise_mode=AZ_NOISE_EXPLICIT, precision=AZ_PREC_FP16,
-                 seed=0, device=0, game_slot_base=0, leaves_per_round=1):
+                 seed=0, device=0, game_slot_base=0, leaves_per_round=1, c_in=0, c_out=0, value_dim=0):
         L = load()
         cfg = AzConfig()
         cfg.device, cfg.N, cfg.K, cfg.G = device, N, K, G
@@ -155,6 +157,8 @@ class Engine:
         cfg.eval_mode, cfg.noise_mode, cfg.precision = eval_mode, noise_mode, precision
         cfg.seed, cfg.game_slot_base = seed, game_slot_base
         cfg.leaves_per_round = leaves_per_round
+        cfg.c_in, cfg.c_out, cfg.value_dim = c_in, c_out, value_dim
+        self.c_in, self.c_out, self.value_dim = c_in or 3, c_out or 1, value_dim or 2
         self.L = max(1, leaves_per_round)
         self.N, self.K, self.G, self.A = N, K, G, N * N
         self.Cs = Cs
@@ -183,8 +187,8 @@ class Engine:
     def tower_forward(self, boards):
         boards = np.ascontiguousarray(boards, np.uint8)
         B = boards.shape[0]
-        pol = np.empty((B, self.A), np.float32)
-        val = np.empty((B, 2), np.float32)
+        pol = np.empty((B, self.c_out * self.A), np.float32)
+        val = np.empty((B, self.value_dim), np.float32)
         _chk(load().az_tower_forward(self.h, _ptr(boards), B, _ptr(pol), _ptr(val)))
         return pol, val
 
@@ -427,6 +431,15 @@ class Blokus:
 
     def search(self, budget):
         _chk(load().az_blokus_search(self.h, int(budget)))
+
+    def search_tower(self, tower_engine, budget):
+        """search with the leaves evaluated by `tower_engine` (an Engine with N=20, c_in=5, c_out=91, value_dim=4)"""
+        _chk(load().az_blokus_search_tower(self.h, tower_engine.h, int(budget)))
+
+    def eval_io(self):
+        pl, po, va = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _chk(load().az_blokus_eval_io(self.h, C.byref(pl), C.byref(po), C.byref(va)))
+        return pl.value, po.value, va.value
 
     def search_result(self, game):
         L = load()

@@ -49,6 +49,7 @@ struct az_ctx {
     AzTreeDev d;
     std::vector<void*> allocs;
     int A = 0, P = 0, W = 0, Gd = 0, C = 0, C_pad = 0, num_res = 0;
+    int c_in = 3, c_out = 1, vd = 2;                      // tower input planes, policy channels, value entries
     int Bmax = 0;
     // tower
     bool have_weights = false;
@@ -110,11 +111,11 @@ static int dalloc(az_ctx* c, T** p, size_t n, bool zero = true) {
     return AZ_OK;
 }
 
-static size_t weights_size(int N, int c_in, const int* Cs, int n_Cs) {
+static size_t weights_size(int N, int c_in, int c_out, int vd, const int* Cs, int n_Cs) {
     auto conv = [](size_t ci, size_t co, size_t k) { return co * ci * k * k + co; };
     const int num_res = n_Cs - 1, Ch = Cs[num_res - 1];
-    size_t s = conv(c_in, Cs[0], 3) + 4 * (size_t)Cs[0] + conv(Ch, 1, 1) + conv(Ch, 1, 1) + 4 +
-               (size_t)64 * N * N + 64 + 128 + 2;
+    size_t s = conv(c_in, Cs[0], 3) + 4 * (size_t)Cs[0] + conv(Ch, c_out, 1) + conv(Ch, 1, 1) + 4 +
+               (size_t)64 * N * N + 64 + 64 * (size_t)vd + vd;
     for (int i = 0; i < num_res; ++i) s += conv(Cs[i], Cs[i + 1], 3) + conv(Cs[i + 1], Cs[i + 1], 3) + 8 * (size_t)Cs[i + 1];
     return s;
 }
@@ -136,6 +137,8 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
                 return fail(AZ_E_ARG, "ResBlock widths must be uniform (x + input, network.hpp:36)");
         if (cfg->precision != AZ_PREC_BF16 && cfg->precision != AZ_PREC_FP16)
             return fail(AZ_E_ARG, "precision %d unknown (AZ_PREC_BF16, AZ_PREC_FP16)", cfg->precision);
+        if (cfg->c_in < 0 || cfg->c_in > 16 || cfg->c_out < 0 || cfg->c_out > 128 || cfg->value_dim < 0 || cfg->value_dim > 8 || cfg->value_dim == 1)
+            return fail(AZ_E_ARG, "tower shape out of range: c_in %d (<= 16), c_out %d (<= 128), value_dim %d (2..8)", cfg->c_in, cfg->c_out, cfg->value_dim);
     }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -216,9 +219,11 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         c->C_pad = (c->C + 127) / 128 * 128;
         c->num_res = cfg->n_Cs - 1;
         c->prec = cfg->precision == AZ_PREC_BF16 ? 0 : 1;           // kernel template index: 0 bf16, 1 fp16
+        c->c_in = cfg->c_in > 0 ? cfg->c_in : 3; c->c_out = cfg->c_out > 0 ? cfg->c_out : 1; c->vd = cfg->value_dim > 0 ? cfg->value_dim : 2;
+        const bool mnk_shape = c->c_in == 3 && c->c_out == 1 && c->vd == 2;
         // whole tower in one launch when a board fits one 256-row LDS tile and the bias table of all
         // layers still fits beside it (160 KB per CU); otherwise one launch per convolution
-        c->fused = c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED") &&
+        c->fused = mnk_shape && c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED") &&
                    az_tower_fused_lds_bytes(N, 2 * c->num_res, 256) <= 160 * 1024;
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
         AZCHK(dalloc(c, &c->stem_b, c->C_pad));
@@ -233,13 +238,15 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
             AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->actR, c->act_rows * c->C_pad));
-            AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * 27));
+            if (az_tower_heads_lds_bytes(N, c->C_pad, c->c_out) > 128 * 1024 || az_tower_stem_lds_bytes(N, c->C_pad, c->c_in) > 64 * 1024)
+                return fail(AZ_E_ARG, "tower heads do not fit LDS: c_out %d x %d channels, c_in %d", c->c_out, c->C_pad, c->c_in);
+            AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * c->c_in * 9));
             AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
-            AZCHK(dalloc(c, &c->head_p, (size_t)2 * c->C_pad + 2 + 64 * (size_t)A + 64 + 128 + 2));
+            AZCHK(dalloc(c, &c->head_p, (size_t)(c->c_out + 1) * c->C_pad + c->c_out + 1 + 64 * (size_t)A + 64 + 64 * (size_t)c->vd + c->vd));
         }
-        AZCHK(dalloc(c, &c->blob_stage, weights_size(N, 3, cfg->Cs, cfg->n_Cs), false));
-        AZCHK(dalloc(c, &c->tower_in, (size_t)c->Bmax * 3 * A));
-        AZCHK(dalloc(c, &c->tower_pol, (size_t)c->Bmax * A)); AZCHK(dalloc(c, &c->tower_val, 2 * (size_t)c->Bmax));
+        AZCHK(dalloc(c, &c->blob_stage, weights_size(N, c->c_in, c->c_out, c->vd, cfg->Cs, cfg->n_Cs), false));
+        AZCHK(dalloc(c, &c->tower_in, (size_t)c->Bmax * c->c_in * A));
+        AZCHK(dalloc(c, &c->tower_pol, (size_t)c->Bmax * c->c_out * A)); AZCHK(dalloc(c, &c->tower_val, (size_t)c->vd * c->Bmax));
         if (az_tower_configure() != 0) return fail(AZ_E_HIP, "tower kernel LDS configuration failed");
     }
     HIPCHK(hipDeviceSynchronize());
@@ -264,6 +271,16 @@ extern "C" int az_device_count(void) {
 }
 extern "C" int az_tower_is_fused(const az_ctx* c) { return c && c->fused ? 1 : 0; }
 extern "C" int az_ctx_cells(const az_ctx* c) { return c ? c->A : 0; }
+extern "C" int az_tower_shape(const az_ctx* c, int* N, int* c_in, int* c_out, int* value_dim, int* max_batch) {
+    NEED(c);
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    if (N) *N = c->cfg.N;
+    if (c_in) *c_in = c->c_in;
+    if (c_out) *c_out = c->c_out;
+    if (value_dim) *value_dim = c->vd;
+    if (max_batch) *max_batch = c->Bmax;
+    return AZ_OK;
+}
 extern "C" int az_selfplay_batch(const az_ctx* c) { return c ? c->cfg.G * c->d.L : 0; }
 extern "C" int az_sync(az_ctx* c) { NEED(c); return sync_all(c); }
 extern "C" void* az_stream(az_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -271,7 +288,7 @@ extern "C" void* az_stream(az_ctx* c) { return c ? (void*)c->stream : nullptr; }
 // ----------------------------------------------------------------- weights
 extern "C" size_t az_weights_size(const az_ctx* c) {
     if (!c || c->cfg.eval_mode != AZ_EVAL_TOWER) return 0;
-    return weights_size(c->cfg.N, 3, c->cfg.Cs, c->cfg.n_Cs);
+    return weights_size(c->cfg.N, c->c_in, c->c_out, c->vd, c->cfg.Cs, c->cfg.n_Cs);
 }
 
 // load_network (util.h:60-105) minus the file: the blob is staged on the device, validated there, and
@@ -284,13 +301,14 @@ static int load_weights_staged(az_ctx* c) {
     a.blob = c->blob_stage; a.n_floats = az_weights_size(c);
     a.N = N; a.A = A; a.C = C; a.Cp = c->C_pad; a.nres = c->num_res;
     a.fused = c->fused ? 1 : 0; a.prec = c->prec;
+    a.c_in = c->c_in; a.c_out = c->c_out; a.vd = c->vd;
     size_t o = 0;                                            // module registration order: CBlock, PHead, VHead, RBlock_i
-    a.off_stem_w = o; o += (size_t)C * 27 + C;
+    a.off_stem_w = o; o += (size_t)C * c->c_in * 9 + C;
     a.off_stem_bn = o; o += 4 * (size_t)C;
-    a.off_pc = o; o += (size_t)C + 1;
+    a.off_pc = o; o += (size_t)C * c->c_out + c->c_out;
     a.off_vc = o; o += (size_t)C + 1;
     a.off_vbn = o; o += 4;
-    a.off_fc1 = o; o += (size_t)64 * A + 64 + 128 + 2;
+    a.off_fc1 = o; o += (size_t)64 * A + 64 + 64 * (size_t)c->vd + c->vd;
     a.off_res0 = o; a.res_stride = 2 * ((size_t)9 * C * C + C) + 8 * (size_t)C;
     if (o + (size_t)c->num_res * a.res_stride != a.n_floats) return fail(AZ_E_STATE, "blob layout does not add up");
     a.stem_w = c->stem_w; a.stem_b = c->stem_b; a.stem_wbf = c->stem_wbf; a.conv_wf = c->conv_wf; a.conv_w = c->conv_w;
@@ -344,7 +362,7 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
-    az_launch_stem(c->stream, c->prec, planes_dev, actX, actR, c->stem_w, c->stem_b, B, N, Cp, Gd);
+    az_launch_stem(c->stream, c->prec, planes_dev, actX, actR, c->stem_w, c->stem_b, B, N, Cp, Gd, c->c_in);
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
@@ -355,7 +373,7 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         az_launch_conv3x3(c->stream, c->prec, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
     }
-    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd);
+    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd);
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }
@@ -380,10 +398,10 @@ extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* 
     if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t A = c->A;
-    HIPCHK(hipMemcpyAsync(c->tower_in, boards, (size_t)B * 3 * A, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tower_in, boards, (size_t)B * c->c_in * A, hipMemcpyHostToDevice, c->stream));
     AZCHK(tower_run(c, c->tower_in, B, c->tower_pol, c->tower_val));
-    HIPCHK(hipMemcpyAsync(policy, c->tower_pol, (size_t)B * A * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(value, c->tower_val, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(policy, c->tower_pol, (size_t)B * c->c_out * A * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(value, c->tower_val, (size_t)B * c->vd * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AZ_OK;
 }
@@ -577,6 +595,8 @@ extern "C" int az_tree_clear(az_ctx* c) {
 static int run_evaluator(az_ctx* c, int g0, int count) {
     const size_t s0 = (size_t)g0 * c->d.L;
     const int B = count * c->d.L;
+    if (c->cfg.eval_mode == AZ_EVAL_TOWER && !(c->c_in == 3 && c->c_out == 1 && c->vd == 2))
+        return fail(AZ_E_STATE, "this context's tower (c_in %d, c_out %d, value_dim %d) does not fit the m,n,k search", c->c_in, c->c_out, c->vd);
     if (c->cfg.eval_mode == AZ_EVAL_TOWER)
         return tower_run(c, c->d.leaf_planes + s0 * 3 * c->A, B, c->d.policy + s0 * c->A, c->d.value + s0 * 2);
     if (c->cfg.eval_mode == AZ_EVAL_HASH) {

@@ -9,7 +9,7 @@ int  az_tower_configure(void);
 size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows);   // dynamic LDS of az_tower_fused_kernel
 
 void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
-                    const float* bias, int B, int N, int C_pad, int Gd);
+                    const float* bias, int B, int N, int C_pad, int Gd, int c_in);
 void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
                        float* resid, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu);
@@ -17,5 +17,7 @@ void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const
                            const float* stem_b, const unsigned short* wpk, const float* bias,
                            const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers);
 void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
-                     float* value, int B, int N, int C_pad, int Gd);
+                     float* value, int B, int N, int C_pad, int Gd, int c_out, int vd);
+size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out);     // dynamic LDS of az_heads_kernel / az_stem_kernel (<= 64 KB)
+size_t az_tower_stem_lds_bytes(int N, int C_pad, int c_in);
 }

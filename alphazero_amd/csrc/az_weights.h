@@ -9,13 +9,14 @@ struct AzFoldArgs {
     const float* blob;          // device pointer, n_floats values
     size_t n_floats;
     int N, A, C, Cp, nres;
+    int c_in, c_out, vd;        // input planes, policy channels, value entries
     int fused;                  // 1: images of az_tower_fused_kernel, 0: of the per-layer kernels
     int prec;                   // 0 bf16, 1 fp16 operands
-    size_t off_stem_w;          // CBlock.conv.weight [C][3][3][3], then bias [C]
+    size_t off_stem_w;          // CBlock.conv.weight [C][c_in][3][3], then bias [C]
     size_t off_stem_bn;         // CBlock.bn weight, bias, running_mean, running_var [C] each
-    size_t off_pc, off_vc;      // PHead.conv / VHead.conv: weight [C], bias
+    size_t off_pc, off_vc;      // PHead.conv: weight [c_out][C], bias [c_out]; VHead.conv: weight [C], bias
     size_t off_vbn;             // VHead.bn: weight, bias, running_mean, running_var
-    size_t off_fc1;             // VHead.fc1.weight [64][A], fc1.bias [64], fc2.weight [2][64], fc2.bias [2]
+    size_t off_fc1;             // VHead.fc1.weight [64][A], fc1.bias [64], fc2.weight [vd][64], fc2.bias [vd]
     size_t off_res0, res_stride;// RBlock_i at off_res0 + i * res_stride: conv1 w,b; conv2 w,b; bn1; bn2
     // outputs (device)
     float* stem_w;              // per-layer path: [Cp][27]

@@ -571,6 +571,7 @@ struct az_blokus {
     uint8_t* d_export = nullptr;      // [G][91*400] mask or [G][5][400] planes
     int max_budget = 0;
     int64_t rounds = 0;
+    hipEvent_t ev_tree = nullptr, ev_eval = nullptr;      // hand-offs between this stream and a tower context's
 };
 
 static int bfail(int code, const std::string& m) { return az_internal_fail(code, m.c_str()); }
@@ -602,6 +603,7 @@ extern "C" int az_blokus_destroy(az_blokus* b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : b->allocs) (void)hipFree(p);
+    if (b->ev_tree) { (void)hipEventDestroy(b->ev_tree); (void)hipEventDestroy(b->ev_eval); }
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return AZ_OK;
@@ -816,6 +818,34 @@ extern "C" int az_blokus_search(az_blokus* b, int budget) {
         AZB_CHK(az_blokus_search_round(b, &run));
         if (!run) break;
         if (extra > 4 * (bb + 2)) return bfail(AZ_E_STATE, "search did not finish within its round bound");
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_blokus_search_tower(az_blokus* b, az_ctx* tower, int budget) {
+    BNEED(b); BNEED(tower);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    int N = 0, ci = 0, co = 0, vd = 0, mb = 0;
+    AZB_CHK(az_tower_shape(tower, &N, &ci, &co, &vd, &mb));
+    if (N != AZB_N || ci != AZB_PLANES || co != AZB_ORIENTS || vd != AZB_PLAYERS)
+        return bfail(AZ_E_ARG, "the tower must be 20x20 with c_in 5, c_out 91, value_dim 4");
+    if (mb < b->d.G) return bfail(AZ_E_ARG, "the tower context takes batches of " + std::to_string(mb) + ", the search has " + std::to_string(b->d.G) + " games");
+    BHIP(hipSetDevice(b->device));
+    if (!b->ev_tree) { BHIP(hipEventCreateWithFlags(&b->ev_tree, hipEventDisableTiming)); BHIP(hipEventCreateWithFlags(&b->ev_eval, hipEventDisableTiming)); }
+    hipStream_t ts = (hipStream_t)az_stream(tower);
+    AZB_CHK(az_blokus_search_begin(b, budget));
+    const int bb = budget > 1 ? budget : 1;
+    for (int r = 0, extra = 0;; ++r) {
+        int run = 1;
+        AZB_CHK(az_blokus_search_round(b, r < bb + 1 ? nullptr : &run));          // past the expected end: ask who is still searching
+        if (!run) break;
+        if (r >= bb + 1 && ++extra > 4 * (bb + 2)) return bfail(AZ_E_STATE, "search did not finish within its round bound");
+        // the tree kernel's leaves -> the tower (its own stream) -> back: two event hand-offs, no host wait
+        BHIP(hipEventRecord(b->ev_tree, b->stream));
+        BHIP(hipStreamWaitEvent(ts, b->ev_tree, 0));
+        AZB_CHK(az_tower_forward_dev(tower, b->d.leaf_planes, b->d.G, b->d.policy, b->d.value));
+        BHIP(hipEventRecord(b->ev_eval, ts));
+        BHIP(hipStreamWaitEvent(b->stream, b->ev_eval, 0));
     }
     return AZ_OK;
 }

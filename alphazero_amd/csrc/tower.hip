@@ -93,16 +93,16 @@ template <int PR>
 __global__ void __launch_bounds__(256)
 az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out, float* __restrict__ out32,
                const float* __restrict__ w, const float* __restrict__ bias,
-               int N, int C_pad, int Gd) {
+               int N, int C_pad, int Gd, int c_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int A = N * N, W = N + 1, P = W * W;
-    float* s_w = (float*)smem;                       // [C_pad][27]
-    float* s_b = s_w + C_pad * 27;                   // [C_pad]
-    uint8_t* s_in = (uint8_t*)(s_b + C_pad);         // [3][A]
+    const int A = N * N, W = N + 1, P = W * W, KW = c_in * 9;
+    float* s_w = (float*)smem;                       // [C_pad][c_in * 9]
+    float* s_b = s_w + C_pad * KW;                   // [C_pad]
+    uint8_t* s_in = (uint8_t*)(s_b + C_pad);         // [c_in][A]
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < C_pad * 27; i += 256) s_w[i] = w[i];
+    for (int i = threadIdx.x; i < C_pad * KW; i += 256) s_w[i] = w[i];
     for (int i = threadIdx.x; i < C_pad; i += 256) s_b[i] = bias[i];
-    for (int i = threadIdx.x; i < 3 * A; i += 256) s_in[i] = planes[(size_t)b * 3 * A + i];
+    for (int i = threadIdx.x; i < c_in * A; i += 256) s_in[i] = planes[(size_t)b * c_in * A + i];
     __syncthreads();
     const int cpairs = C_pad / 2;
     for (int idx = threadIdx.x; idx < P * cpairs; idx += 256) {
@@ -111,7 +111,7 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
         float a0 = 0.f, a1 = 0.f;
         if (y < N && x < N) {
             a0 = s_b[c]; a1 = s_b[c + 1];
-            for (int ci = 0; ci < 3; ++ci)
+            for (int ci = 0; ci < c_in; ++ci)
                 for (int ky = 0; ky < 3; ++ky) {
                     const int yy = y + ky - 1;
                     if (yy < 0 || yy >= N) continue;
@@ -119,8 +119,8 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
                         const int xx = x + kx - 1;
                         if (xx < 0 || xx >= N) continue;
                         const float v = (float)s_in[ci * A + yy * N + xx];
-                        a0 += v * s_w[c * 27 + ci * 9 + ky * 3 + kx];
-                        a1 += v * s_w[(c + 1) * 27 + ci * 9 + ky * 3 + kx];
+                        a0 += v * s_w[c * KW + ci * 9 + ky * 3 + kx];
+                        a1 += v * s_w[(c + 1) * KW + ci * 9 + ky * 3 + kx];
                     }
                 }
             a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f);
@@ -1277,57 +1277,86 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 }
 
 // ------------------------------------------------------------------- heads
-// One block per board.  PolicyHead: 1x1 conv -> softmax over the N*N cells.
-// ValueHead: 1x1 conv -> BN(1) -> ReLU -> fc1 (N*N -> 64) -> ReLU -> fc2 -> softmax*2-1.
-// hp layout (fp32): wp[C_pad], wv[C_pad], {bp, bv (BN folded into wv/bv)}, then
-// fc1w [64][A], fc1b [64], fc2w [2][64], fc2b [2].
+// One block per board.  PolicyHead (network.hpp:51-60): 1x1 conv to c_out channels -> softmax over the
+// c_out*N*N entries (layout [c_out][N][N] = get_action_shape()).  ValueHead (network.hpp:75-83): 1x1 conv ->
+// BN(1) -> ReLU -> fc1 (N*N -> 64) -> ReLU -> fc2 (64 -> vd) -> softmax*2-1 (vd = 2 in the reference; a game
+// with more players asks for one entry per player).
+// hp layout (fp32): wp[c_out][C_pad], wv[C_pad], bp[c_out], bv (BN folded into wv/bv), then
+// fc1w [64][A], fc1b [64], fc2w [vd][64], fc2b [vd].  The logits pass through the output buffer.
 template <int PR>
 __global__ void __launch_bounds__(256)
 az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const float* __restrict__ hp,
-                float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd) {
+                float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd, int c_out, int vd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int A = N * N, W = N + 1, P = W * W;
-    float* s_logit = (float*)smem;                   // [A]
-    float* s_u = s_logit + A;                        // [A]
+    float* s_wp = (float*)smem;                      // [c_out][C_pad]
+    float* s_u = s_wp + c_out * C_pad;               // [A]
     float* s_red = s_u + A;                          // [256]
     float* s_f1 = s_red + 256;                       // [64]
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* wp = hp;
-    const float* wvv = hp + C_pad;
-    const float bp = hp[2 * C_pad], bvv = hp[2 * C_pad + 1];
-    const float* fc1w = hp + 2 * C_pad + 2;
+    const float* wvv = hp + (size_t)c_out * C_pad;
+    const float* bp = wvv + C_pad;
+    const float bvv = bp[c_out];
+    const float* fc1w = bp + c_out + 1;
     const float* fc1b = fc1w + 64 * A;
     const float* fc2w = fc1b + 64;
-    const float* fc2b = fc2w + 128;
+    const float* fc2b = fc2w + 64 * vd;
+    float* pol = policy + (size_t)b * c_out * A;
+    for (int i = tid; i < c_out * C_pad; i += 256) s_wp[i] = hp[i];
+    __syncthreads();
 
-    for (int a = tid; a < A; a += 256) {
+    // Both 1x1 convolutions.  Work items = (cell, group of <= 24 policy channels): an item holds 128 channels
+    // of its cell's row in registers and runs them against the group's weights (LDS, the same address for
+    // every lane: broadcast reads), so a 91-channel head keeps all 256 threads busy and reads a row four
+    // times, not 92.  The logits pass through the output buffer.
+    const int ncg = (c_out + 23) / 24, cgs = (c_out + ncg - 1) / ncg;
+    for (int item = tid; item < A * ncg; item += 256) {
+        const int a = item % A, cg = item / A;
         const int y = a / N, xx = a % N;
         const float* row = x + ((size_t)(Gd + b * P + y * W + xx)) * C_pad;
-        float sp = 0.f, sv = 0.f;
-        for (int c = 0; c < C_pad; c += 4) {
-            const float4 v = *(const float4*)(row + c);
-            sp += v.x * wp[c] + v.y * wp[c + 1] + v.z * wp[c + 2] + v.w * wp[c + 3];
-            sv += v.x * wvv[c] + v.y * wvv[c + 1] + v.z * wvv[c + 2] + v.w * wvv[c + 3];
+        const int co0 = cg * cgs, co1 = min(c_out, co0 + cgs);
+        float sv = 0.f;
+        for (int ch0 = 0; ch0 < C_pad; ch0 += 128) {
+            float4 r[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) r[q] = *(const float4*)(row + ch0 + 4 * q);
+            if (cg == 0) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    const float4 w4 = *(const float4*)(wvv + ch0 + 4 * q);
+                    sv += r[q].x * w4.x + r[q].y * w4.y + r[q].z * w4.z + r[q].w * w4.w;
+                }
+            }
+            for (int co = co0; co < co1; ++co) {
+                const float* wp = s_wp + co * C_pad + ch0;
+                float sp = 0.f;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    const float4 w4 = *(const float4*)(wp + 4 * q);
+                    sp += r[q].x * w4.x + r[q].y * w4.y + r[q].z * w4.z + r[q].w * w4.w;
+                }
+                pol[co * A + a] = ch0 == 0 ? sp + bp[co] : pol[co * A + a] + sp;
+            }
         }
-        s_logit[a] = sp + bp;
-        s_u[a] = fmaxf(sv + bvv, 0.f);
+        if (cg == 0) s_u[a] = fmaxf(sv + bvv, 0.f);
     }
     __syncthreads();
-    // softmax over the A cells
+    // softmax over the c_out * A entries
+    const int n_pol = c_out * A;
     float mx = -3.4e38f;
-    for (int a = tid; a < A; a += 256) mx = fmaxf(mx, s_logit[a]);
+    for (int i = tid; i < n_pol; i += 256) mx = fmaxf(mx, pol[i]);
     s_red[tid] = mx;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]); __syncthreads(); }
     mx = s_red[0];
     __syncthreads();
     float sum = 0.f;
-    for (int a = tid; a < A; a += 256) { const float e = expf(s_logit[a] - mx); s_logit[a] = e; sum += e; }
+    for (int i = tid; i < n_pol; i += 256) { const float e = expf(pol[i] - mx); pol[i] = e; sum += e; }
     s_red[tid] = sum;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
     sum = s_red[0];
-    for (int a = tid; a < A; a += 256) policy[(size_t)b * A + a] = s_logit[a] / sum;
+    for (int i = tid; i < n_pol; i += 256) pol[i] = pol[i] / sum;
     // value: fc1 with 4 threads per output
     {
         const int o = tid >> 2, part = tid & 3;
@@ -1339,14 +1368,18 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     }
     __syncthreads();
     if (tid < 64) {
-        float z0 = fc2w[tid] * s_f1[tid], z1 = fc2w[64 + tid] * s_f1[tid];
-        for (int o = 32; o > 0; o >>= 1) { z0 += __shfl_xor(z0, o, 64); z1 += __shfl_xor(z1, o, 64); }
+        float z[8];
+        float m2 = -3.4e38f;
+        for (int k = 0; k < vd; ++k) {
+            float zk = fc2w[k * 64 + tid] * s_f1[tid];
+            for (int o = 32; o > 0; o >>= 1) zk += __shfl_xor(zk, o, 64);
+            z[k] = zk + fc2b[k];
+            m2 = fmaxf(m2, z[k]);
+        }
         if (tid == 0) {
-            z0 += fc2b[0]; z1 += fc2b[1];
-            const float m2 = fmaxf(z0, z1);
-            const float e0 = expf(z0 - m2), e1 = expf(z1 - m2);
-            value[2 * b] = e0 / (e0 + e1) * 2.f - 1.f;
-            value[2 * b + 1] = e1 / (e0 + e1) * 2.f - 1.f;
+            float den = 0.f;
+            for (int k = 0; k < vd; ++k) { z[k] = expf(z[k] - m2); den += z[k]; }
+            for (int k = 0; k < vd; ++k) value[(size_t)vd * b + k] = z[k] / den * 2.f - 1.f;
         }
     }
 }
@@ -1360,12 +1393,20 @@ extern "C" size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows) {
            (size_t)(rows / P) * 3 * N * N + 16;
 }
 
+extern "C" size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out) {
+    return ((size_t)c_out * C_pad + (size_t)N * N + 256 + 64) * 4;
+}
+extern "C" size_t az_tower_stem_lds_bytes(int N, int C_pad, int c_in) {
+    return (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
+}
+
 extern "C" int az_tower_configure(void) {
     hipError_t e = hipSuccess;
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
+    SETA(az_heads_kernel<0>, 128 * 1024); SETA(az_heads_kernel<1>, 128 * 1024);
     SETA((az_tower_fused_kernel<0, 2, 32>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2, 32>), 160 * 1024);
     SETA((az_tower_fused_kernel<0, 1, 32>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1, 32>), 160 * 1024);
     SETA((az_tower_fused_kernel<0, 2, 16>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2, 16>), 160 * 1024);
@@ -1378,9 +1419,9 @@ extern "C" int az_tower_configure(void) {
 #define BY_PREC(kern, ...) do { if (prec == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
 
 extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
-                               const float* bias, int B, int N, int C_pad, int Gd) {
-    const size_t sm = (size_t)C_pad * 28 * 4 + 3 * N * N + 16;
-    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, w, bias, N, C_pad, Gd);
+                               const float* bias, int B, int N, int C_pad, int Gd, int c_in) {
+    const size_t sm = (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
+    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, w, bias, N, C_pad, Gd, c_in);
 }
 
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
@@ -1430,7 +1471,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
-                                float* value, int B, int N, int C_pad, int Gd) {
-    const size_t sm = (size_t)(2 * N * N + 256 + 64) * 4;
-    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd);
+                                float* value, int B, int N, int C_pad, int Gd, int c_out, int vd) {
+    const size_t sm = az_tower_heads_lds_bytes(N, C_pad, c_out);
+    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd, c_out, vd);
 }

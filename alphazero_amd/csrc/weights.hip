@@ -72,35 +72,40 @@ __global__ void __launch_bounds__(256) az_fold_conv_kernel(AzFoldArgs a) {
 
 // Stem and heads: one block.
 __global__ void __launch_bounds__(256) az_fold_small_kernel(AzFoldArgs a) {
-    const int C = a.C, Cp = a.Cp, A = a.A;
+    const int C = a.C, Cp = a.Cp, A = a.A, KW = a.c_in * 9;
     const float* sw = a.blob + a.off_stem_w;
-    const float* sb = sw + (size_t)C * 27;
+    const float* sb = sw + (size_t)C * KW;
     const float* sbn = a.blob + a.off_stem_bn;
-    for (int e = threadIdx.x; e < C * 27; e += 256) {
-        const int co = e / 27, k = e % 27;
+    for (int e = threadIdx.x; e < C * KW; e += 256) {
+        const int co = e / KW, k = e % KW;
         const float f = (float)(sw[e] * bn_scale(sbn, C, co));
         if (a.fused) a.stem_wbf[(size_t)co * 32 + k] = w_to16(f, a.prec);
         else a.stem_w[e] = f;
     }
     for (int co = threadIdx.x; co < C; co += 256) a.stem_b[co] = bn_bias(sbn, C, co, sb[co], bn_scale(sbn, C, co));
     // heads: policy 1x1 as is; value 1x1 with its one-channel BatchNorm folded
-    const float* pc = a.blob + a.off_pc;                      // w[C], b
+    const float* pc = a.blob + a.off_pc;                      // w[c_out][C], b[c_out]
     const float* vc = a.blob + a.off_vc;                      // w[C], b
     const float* vbn = a.blob + a.off_vbn;                    // weight, bias, mean, var
     const double vs = bn_scale(vbn, 1, 0);
-    const float* fc1w = a.blob + a.off_fc1;                   // [64][A], then fc1b[64], fc2w[2][64], fc2b[2]
+    const float* fc1w = a.blob + a.off_fc1;                   // [64][A], then fc1b[64], fc2w[vd][64], fc2b[vd]
     const float bvf = bn_bias(vbn, 1, 0, vc[C], vs);
-    if (a.fused) {
+    const int tail = 64 + 64 * a.vd + a.vd;
+    if (a.fused) {                                            // c_out = 1, vd = 2
         float* ht = a.head_pt;                                // {policy, value} weight pairs, biases at [256], [257]
         for (int ch = threadIdx.x; ch < C; ch += 256) { ht[2 * ch] = pc[ch]; ht[2 * ch + 1] = (float)(vc[ch] * vs); }
         if (threadIdx.x == 0) { ht[256] = pc[C]; ht[257] = bvf; }
         for (int e = threadIdx.x; e < 64 * A; e += 256) ht[258 + (size_t)(e % A) * 64 + e / A] = fc1w[e];   // fc1 transposed [A][64]
-        for (int e = threadIdx.x; e < 64 + 128 + 2; e += 256) ht[258 + (size_t)64 * A + e] = fc1w[(size_t)64 * A + e];
+        for (int e = threadIdx.x; e < tail; e += 256) ht[258 + (size_t)64 * A + e] = fc1w[(size_t)64 * A + e];
     } else {
-        float* hp = a.head_p;                                 // wp[Cp], wv[Cp], bp, bv, fc1w [64][A], fc1b, fc2w, fc2b
-        for (int ch = threadIdx.x; ch < C; ch += 256) { hp[ch] = pc[ch]; hp[Cp + ch] = (float)(vc[ch] * vs); }
-        if (threadIdx.x == 0) { hp[2 * Cp] = pc[C]; hp[2 * Cp + 1] = bvf; }
-        for (int e = threadIdx.x; e < 64 * A + 64 + 128 + 2; e += 256) hp[2 * Cp + 2 + e] = fc1w[e];
+        float* hp = a.head_p;                                 // wp[c_out][Cp], wv[Cp], bp[c_out], bv, fc1w [64][A], fc1b, fc2w, fc2b
+        for (int e = threadIdx.x; e < a.c_out * C; e += 256) hp[(size_t)(e / C) * Cp + e % C] = pc[e];
+        float* wv = hp + (size_t)a.c_out * Cp;
+        for (int ch = threadIdx.x; ch < C; ch += 256) wv[ch] = (float)(vc[ch] * vs);
+        float* bp = wv + Cp;
+        for (int co = threadIdx.x; co < a.c_out; co += 256) bp[co] = pc[(size_t)a.c_out * C + co];
+        if (threadIdx.x == 0) bp[a.c_out] = bvf;
+        for (int e = threadIdx.x; e < 64 * A + tail; e += 256) bp[a.c_out + 1 + e] = fc1w[e];
     }
 }
 

@@ -29,7 +29,7 @@ def uniform01(seed, n, offset=0):
     return (r >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
 
 
-def blob_layout(N, c_in, Cs, c_out=1):
+def blob_layout(N, c_in, Cs, c_out=1, value_dim=2):
     """[(name, shape)] in blob order."""
     num_res = len(Cs) - 1
     Ch = Cs[num_res - 1]
@@ -50,8 +50,8 @@ def blob_layout(N, c_in, Cs, c_out=1):
     bn("VHead.bn", 1)
     L.append(("VHead.fc1.weight", (64, N * N)))
     L.append(("VHead.fc1.bias", (64,)))
-    L.append(("VHead.fc2.weight", (2, 64)))
-    L.append(("VHead.fc2.bias", (2,)))
+    L.append(("VHead.fc2.weight", (value_dim, 64)))
+    L.append(("VHead.fc2.bias", (value_dim,)))
     for i in range(num_res):
         r = "RBlock_%d" % i
         conv(r + ".conv1", Cs[i], Cs[i + 1], 3)
@@ -61,16 +61,16 @@ def blob_layout(N, c_in, Cs, c_out=1):
     return L
 
 
-def blob_size(N, c_in, Cs, c_out=1):
-    return int(sum(int(np.prod(s)) for _, s in blob_layout(N, c_in, Cs, c_out)))
+def blob_size(N, c_in, Cs, c_out=1, value_dim=2):
+    return int(sum(int(np.prod(s)) for _, s in blob_layout(N, c_in, Cs, c_out, value_dim)))
 
 
-def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1):
+def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1, value_dim=2):
     """Random-init weights: conv/linear U(-1/sqrt(fan_in), +), BN statistics
     randomised so that folding is exercised; head gains sharpen the outputs."""
     parts = []
     off = 0
-    for name, shape in blob_layout(N, c_in, Cs, c_out):
+    for name, shape in blob_layout(N, c_in, Cs, c_out, value_dim):
         n = int(np.prod(shape))
         u = uniform01(seed, n, off)
         off += n
@@ -100,10 +100,10 @@ def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1):
     return np.concatenate(parts)
 
 
-def unpack_blob(blob, N, c_in, Cs, c_out=1):
+def unpack_blob(blob, N, c_in, Cs, c_out=1, value_dim=2):
     out = {}
     off = 0
-    for name, shape in blob_layout(N, c_in, Cs, c_out):
+    for name, shape in blob_layout(N, c_in, Cs, c_out, value_dim):
         n = int(np.prod(shape))
         out[name] = blob[off:off + n].reshape(shape)
         off += n
@@ -123,3 +123,17 @@ def random_boards(B, N, seed=0, occupancy=0.3):
     planes[:, 1] = p1
     planes[:, 2] = side[:, None]
     return planes.reshape(B, 3, N, N)
+
+
+def random_planes(B, c_in, N, seed=0, occupancy=0.35):
+    """u8 planes [B,c_in,N,N] for a tower with c_in input planes: c_in - 1 disjoint stone planes and a last
+    plane filled with the player to move (0 .. c_in - 2), the shape of the Blokus planes."""
+    A = N * N
+    u = uniform01(seed + 3000, B * A).reshape(B, A)
+    side = (uniform01(seed + 4000, B) * (c_in - 1)).astype(np.uint8)
+    planes = np.zeros((B, c_in, A), np.uint8)
+    owners = c_in - 1
+    for p in range(owners):
+        planes[:, p] = (u >= occupancy * p / owners) & (u < occupancy * (p + 1) / owners)
+    planes[:, c_in - 1] = side[:, None]
+    return planes.reshape(B, c_in, N, N)

@@ -72,6 +72,11 @@ typedef struct az_config {
                                      defined order: descents in sequence under virtual loss, one batched
                                      evaluation of the G*L slots, backups in descent order; a descent that
                                      meets a stub already awaiting evaluation is undone and ends the round */
+    /* PVNetwork(board, Cs, in, out) (network.hpp:104): input planes and policy channels of the tower, 0 = the
+     * m,n,k environments' 3 and 1; value_dim = entries of the value head, 0 = the reference's 2
+     * (network.hpp:73,81).  Other values (Blokus: 5, 91, 4) give a context whose tower is used through
+     * az_tower_forward*; its m,n,k search entry points return AZ_E_STATE. */
+    int   c_in, c_out, value_dim;
 } az_config;
 
 typedef struct az_stats {
@@ -131,9 +136,12 @@ int az_env_load(az_ctx*, const int32_t* hist, const int32_t* hist_len);
 
 /* PVNetwork::forward (network.hpp:117-123) in eval mode as driven by
  * Evaluator::run (evaluator.hpp:113-117): boards u8 [B,3,N,N] ->
- * policy f32 [B,N*N] (softmax probabilities), value f32 [B,2]. */
+ * policy f32 [B,c_out*N*N] (softmax probabilities), value f32 [B,value_dim]. */
 int az_tower_forward(az_ctx*, const uint8_t* boards, int B, float* policy, float* value);
 int az_tower_forward_dev(az_ctx*, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev);
+/* PVNetwork's constructor arguments as the context holds them (network.hpp:104): board side, `in`, `out`,
+ * value entries, and the largest batch one call takes (any pointer may be NULL) */
+int az_tower_shape(const az_ctx*, int* N, int* c_in, int* c_out, int* value_dim, int* max_batch);
 
 /* No counterpart in the reference.  az_tower_forward_dev for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): on a context
@@ -250,6 +258,10 @@ void* az_blokus_stream(az_blokus*);
 int az_blokus_search_config(az_blokus*, float vl, float c_puct, int max_budget, int edge_cap);
 int az_blokus_set_noise(az_blokus*, const float* noise /* [G,n] or NULL = no noise */, int n);
 int az_blokus_search(az_blokus*, int budget);
+/* the same search with the leaves evaluated by `tower`, a context created with N = 20, c_in = 5, c_out = 91,
+ * value_dim = 4 and G >= the number of Blokus games, on the same GPU (the Evaluator + PVNetwork pair of
+ * evaluator.hpp:80-124 / network.hpp:117-123 for this Env): nothing leaves the device between the rounds */
+int az_blokus_search_tower(az_blokus*, az_ctx* tower, int budget);
 int az_blokus_search_begin(az_blokus*, int budget);
 int az_blokus_search_round(az_blokus*, int* n_running /* or NULL */);
 int az_blokus_eval_hash(az_blokus*);

@@ -43,6 +43,9 @@ TOWER_CASES = [
     # BASELINE configs[4]: 20 ResBlocks x 256 channels (41 convolutions deep), random-init and sharpened heads
     ("n15_c256x21", 15, [256] * 21, 8, 8, 1.0, 1.0),
     ("n15_c256x21_sharp", 15, [256] * 21, 8, 9, 20.0, 20.0),
+    # the Blokus tower shape: 20x20 board, 5 input planes, 91 policy channels (network.hpp:104 `in`, `out`),
+    # the reference's two-entry value head
+    ("n20_in5_out91", 20, synth.NETCONFIG2, 2, 10, 6.0, 4.0, 5, 91),
 ]
 
 
@@ -58,18 +61,18 @@ def gen_mcts(name, N, K, budget, n_moves, noise_seed, wseed):
     print("mcts", name, "steps", int(z["meta"][3]), "table", len(z["table_value"]))
 
 
-def gen_tower(name, N, Cs, B, wseed, pg, fg):
-    blob = synth.make_blob(N, 3, Cs, wseed, pg, fg)
-    boards = synth.random_boards(B, N, seed=wseed)
+def gen_tower(name, N, Cs, B, wseed, pg, fg, c_in=3, c_out=1):
+    blob = synth.make_blob(N, c_in, Cs, wseed, pg, fg, c_out=c_out)
+    boards = synth.random_boards(B, N, seed=wseed) if c_in == 3 else synth.random_planes(B, c_in, N, seed=wseed)
     with tempfile.TemporaryDirectory() as d:
         blob.tofile(os.path.join(d, "blob.bin"))
         boards.tofile(os.path.join(d, "boards.bin"))
-        subprocess.check_call([REF, "tower", str(N), "3", os.path.join(d, "blob.bin"), os.path.join(d, "boards.bin"),
-                               str(B), os.path.join(d, "out")] + [str(c) for c in Cs])
+        subprocess.check_call([REF, "tower", str(N), str(c_in), os.path.join(d, "blob.bin"), os.path.join(d, "boards.bin"),
+                               str(B), os.path.join(d, "out")] + [str(c) for c in Cs], env=dict(os.environ, AZ_REF_COUT=str(c_out)))
         pol = np.load(os.path.join(d, "out_policy.npy"))
         val = np.load(os.path.join(d, "out_value.npy"))
     np.savez_compressed(os.path.join(OUT, "tower_%s.npz" % name), N=N, Cs=np.array(Cs), B=B, wseed=wseed,
-                        phead_gain=pg, fc2_gain=fg, boards=boards, policy=pol, value=val)
+                        phead_gain=pg, fc2_gain=fg, boards=boards, policy=pol, value=val, c_in=c_in, c_out=c_out)
     print("tower", name, "pmax", pol.max(), "v", val.min(), val.max())
 
 

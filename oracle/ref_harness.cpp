@@ -115,7 +115,9 @@ static int cmd_tower(int argc, char** argv) {
     const std::string out_prefix = argv[7];
     std::vector<int> Cs;
     for (int i = 8; i < argc; ++i) Cs.push_back(atoi(argv[i]));
-    PVNetwork net(N, Cs, c_in, 1);
+    const char* co_env = getenv("AZ_REF_COUT");                 /* policy channels (network.hpp:104 `out`), default 1 */
+    const int c_out = co_env ? atoi(co_env) : 1;
+    PVNetwork net(N, Cs, c_in, c_out);
     size_t n = 0;
     for (auto& p : net->parameters()) n += p.numel();
     for (auto& kv : net->named_buffers())
@@ -126,16 +128,16 @@ static int cmd_tower(int argc, char** argv) {
     torch::NoGradGuard g;
     auto boards = load_raw<uint8_t>(boards_path, (size_t)B * c_in * N * N);
     auto X = torch::from_blob(boards.data(), {B, c_in, N, N}, torch::kUInt8).to(torch::kFloat32);
-    std::vector<float> pol((size_t)B * N * N), val((size_t)B * 2);
+    std::vector<float> pol((size_t)B * c_out * N * N), val((size_t)B * 2);
     for (int b0 = 0; b0 < B; b0 += 16) {      /* evaluator.hpp:113-114, batch <= 16 */
         const int b1 = std::min(B, b0 + 16);
         torch::Tensor p, v;
         std::tie(p, v) = net(X.slice(0, b0, b1));
         p = p.contiguous(); v = v.contiguous();
-        memcpy(pol.data() + (size_t)b0 * N * N, p.data_ptr<float>(), sizeof(float) * p.numel());
+        memcpy(pol.data() + (size_t)b0 * c_out * N * N, p.data_ptr<float>(), sizeof(float) * p.numel());
         memcpy(val.data() + (size_t)b0 * 2, v.data_ptr<float>(), sizeof(float) * v.numel());
     }
-    save_npy(out_prefix + "_policy.npy", pol, {(size_t)B, (size_t)N * N});
+    save_npy(out_prefix + "_policy.npy", pol, {(size_t)B, (size_t)c_out * N * N});
     save_npy(out_prefix + "_value.npy", val, {(size_t)B, 2});
     return 0;
 }

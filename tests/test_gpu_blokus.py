@@ -191,3 +191,30 @@ def test_search_at_config_size_2048_games_400_sims():
     got = dev.search_result(5)
     for k in ("actions", "n", "v", "p"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_search_with_the_tower_as_evaluator():
+    """The Blokus search fed by the HIP tower (20x20, 5 planes in, 91 policy channels and 4 values out) instead
+    of the hash evaluator, device to device: the root's priors are the tower's softmax at the legal actions
+    (bit for bit: same kernels on the same planes), every simulation is accounted for, values stay in range."""
+    from alphazero_amd import synth
+    G, budget = 16, 24
+    Cs = synth.NETCONFIG2
+    dev = capi.Blokus(G, seed=9)
+    dev.search_config(max_budget=budget)
+    dev.playout(6)
+    dev.sync()
+    tower = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    tower.load_weights(synth.make_blob(20, 5, Cs, 31, phead_gain=4.0, fc2_gain=2.0, c_out=91, value_dim=4))
+    with pytest.raises(capi.AzError, match="c_in 5"):
+        dev.search_tower(capi.Engine(20, 5, G, Cs=Cs, max_budget=1), budget)       # an m,n,k-shaped tower
+    dev.search_tower(tower, budget)
+    pol, val = tower.tower_forward(dev.boards())
+    _, count = dev.legal_mask(want_mask=False)
+    for g in range(G):
+        r = dev.search_result(g)
+        assert r["root_n"] == budget + 1 and r["n"].sum() == budget and len(r["actions"]) == count[g]
+        assert np.array_equal(r["p"], pol[g, r["actions"]])
+        vis = r["n"] > 0
+        assert (np.abs(r["v"][vis] / r["n"][vis]) <= 1.0 + 1e-6).all() and (r["v"][~vis] == 0).all()
+    assert dev.search_stats()["restarts"] == 0

@@ -16,10 +16,10 @@ TOWER_FIX = sorted(glob.glob(os.path.join(GOLDEN, "tower_*.npz")))
 TOL = 1e-3
 
 
-def torch_reference(N, Cs, blob, boards):
+def torch_reference(N, Cs, blob, boards, c_out=1, value_dim=2):
     import torch
     import torch.nn.functional as F
-    w = {k: torch.from_numpy(v.copy()) for k, v in synth.unpack_blob(blob, N, 3, Cs).items()}
+    w = {k: torch.from_numpy(v.copy()) for k, v in synth.unpack_blob(blob, N, boards.shape[1], Cs, c_out, value_dim).items()}
     x = torch.from_numpy(boards.astype(np.float32))
 
     def bn(x, n):
@@ -55,8 +55,9 @@ def _fixture_cases():
 def test_tower_matches_reference_fixture(path, prec):
     z = np.load(path)
     N, Cs, B = int(z["N"]), [int(c) for c in z["Cs"]], int(z["B"])
-    blob = synth.make_blob(N, 3, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]))
-    eng = capi.Engine(N, min(N, 5), B, Cs=Cs, precision=prec)
+    c_in, c_out = (int(z["c_in"]), int(z["c_out"])) if "c_in" in z.files else (3, 1)
+    blob = synth.make_blob(N, c_in, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]), c_out=c_out)
+    eng = capi.Engine(N, min(N, 5), B, Cs=Cs, precision=prec, c_in=c_in, c_out=c_out, max_budget=1)
     eng.load_weights(blob)
     pol, val = eng.tower_forward(z["boards"])
     perr, verr = np.abs(pol - z["policy"]).max(), np.abs(val - z["value"]).max()
@@ -268,3 +269,27 @@ def test_fused_tower_32x32x16_build_matches_the_default_16x16x32_build(monkeypat
         rp, rv = torch_reference(N, Cs, blob, boards)
     for p, v in ((p16, v16), (p32, v32)):
         assert np.abs(p - rp).max() < TOL and np.abs(v - rv).max() < TOL
+
+
+@pytest.mark.parametrize("prec", [capi.AZ_PREC_FP16, capi.AZ_PREC_BF16], ids=["fp16", "bf16"])
+def test_blokus_shaped_tower_matches_torch_fp32(prec):
+    """20x20 board, 5 input planes, 91 policy channels (softmax over 36 400 entries), a four-entry value head:
+    the per-layer tower on the shape the Blokus search feeds, against the torch fp32 statement of
+    network.hpp:117-123 with `in` = 5, `out` = 91 and fc2 64 -> 4."""
+    import torch
+    torch.set_num_threads(8)
+    N, B, Cs = 20, 7, synth.NETCONFIG2
+    blob = synth.make_blob(N, 5, Cs, 123, phead_gain=3.0, fc2_gain=3.0, c_out=91, value_dim=4)
+    planes = synth.random_planes(B, 5, N, seed=123)
+    eng = capi.Engine(N, 5, B, Cs=Cs, precision=prec, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    assert not eng.tower_is_fused() and eng.weights_size() == blob.size
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(planes)
+    assert pol.shape == (B, 91 * 400) and val.shape == (B, 4)
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, planes, c_out=91, value_dim=4)
+    print("blokus-shaped tower prec", prec, "policy err %.3g (max p %.3g) value err %.3g" % (np.abs(pol - rp).max(), rp.max(), np.abs(val - rv).max()))
+    assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
+    assert np.allclose(pol.sum(1), 1.0, atol=1e-4) and np.allclose(val.sum(1), 2.0 - 4.0, atol=1e-5)
+    with pytest.raises(capi.AzError, match="m,n,k search"):
+        eng.search(1)                                   # this context is a tower, not an m,n,k searcher

@@ -36,12 +36,13 @@ def test_mcts_restatement_matches_reference_bit_exact(path):
 def test_tower_restatement_matches_reference(path):
     z = np.load(path)
     N, Cs = int(z["N"]), [int(c) for c in z["Cs"]]
+    c_in, c_out = (int(z["c_in"]), int(z["c_out"])) if "c_in" in z.files else (3, 1)
     if N >= 15:
         B = 1     # the scalar restatement needs ~1 s per 15x15 board
     else:
         B = int(z["B"])
-    blob = synth.make_blob(N, 3, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]))
-    t = azo.Tower(N, 3, Cs, blob)
+    blob = synth.make_blob(N, c_in, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]), c_out=c_out)
+    t = azo.Tower(N, c_in, Cs, blob, c_out=c_out)
     pol, val = t.forward(z["boards"][:B])
     # fp32 vs fp32 with a different summation order: tolerance 2e-5 abs
     assert np.abs(pol - z["policy"][:B]).max() < 2e-5

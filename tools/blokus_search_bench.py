@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[3]: Blokus 20x20 four players, 2048 concurrent games x 400 simulations per search, on the
-device's tree kernel with the integer-hash evaluator (no Blokus tower exists yet: the number is the env + tree
-path alone).  One JSON line; run under `rocprofv3 --kernel-trace --stats` for the per-kernel summary."""
+device's tree kernel, with the integer-hash evaluator (env + tree path alone) or, with --tower, with the HIP
+tower as the leaf evaluator.  One JSON line; run under `rocprofv3 --kernel-trace --stats` for the per-kernel summary."""
 import argparse
 import json
 import os
@@ -18,24 +18,34 @@ def main():
     ap.add_argument("--budget", type=int, default=400)
     ap.add_argument("--pieces", type=int, default=9, help="random pieces on the board before the search")
     ap.add_argument("--searches", type=int, default=3)
+    ap.add_argument("--tower", action="store_true", help="evaluate the leaves with the HIP tower (NetConfig 2 on 20x20, 5 planes in, "
+                                                         "91 policy channels, 4 values) instead of the integer-hash evaluator")
     a = ap.parse_args()
-    from alphazero_amd import capi
+    from alphazero_amd import capi, synth
     dev = capi.Blokus(a.games, seed=3)
     dev.search_config(max_budget=a.budget)
     dev.playout(a.pieces)
     dev.sync()
-    dev.search(8)                                   # warm-up
+    tower = None
+    if a.tower:
+        Cs = synth.NETCONFIG2
+        tower = capi.Engine(20, 5, a.games, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+        tower.load_weights(synth.make_blob(20, 5, Cs, 0, c_out=91, value_dim=4))
+    run = (lambda b: dev.search_tower(tower, b)) if a.tower else dev.search
+    run(8)                                          # warm-up
+    dev.sync()
     t0 = time.perf_counter()
     for _ in range(a.searches):
-        dev.search(a.budget)
+        run(a.budget)
     dev.sync()
     el = time.perf_counter() - t0
     st = dev.search_stats()
     _, count = dev.legal_mask(want_mask=False)
     sims = a.games * a.budget * a.searches
     print(json.dumps({"metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
-                      "config": {"workload": "blokus 20x20 4-player, %d concurrent games x %d sims per search, integer-hash evaluator "
-                                             "(env + tree kernels only; no Blokus tower)" % (a.games, a.budget),
+                      "config": {"workload": "blokus 20x20 4-player, %d concurrent games x %d sims per search, %s" % (
+                                     a.games, a.budget, "NetConfig-2 tower (stem + 9 ResBlocks x 128 ch, 5 planes in, 91 policy channels, 4 values), "
+                                     "fp16 operands, random-init weights" if a.tower else "integer-hash evaluator (env + tree kernels only)"),
                                  "pieces_on_board": a.pieces, "mean_legal_actions_at_root": float(count.mean())},
                       "ms_per_round": el / (a.searches * (a.budget + 3)) * 1e3, "searches": a.searches, "seconds": el, "tree": st}))
 
