@@ -57,7 +57,7 @@ static inline int azb_build_orients(AzbOrient* table) {
                 if (AZB_SHAPES[pc][r][c] == '#') { by[n] = r; bx[n] = c; ++n; }
         const int first = count;
         for (int t = 0; t < 8; ++t) {
-            int y[5], x[5];
+            int y[5] = {0, 0, 0, 0, 0}, x[5] = {0, 0, 0, 0, 0};
             for (int i = 0; i < n; ++i) {
                 int yy = by[i], xx = t >= 4 ? -bx[i] : bx[i];              // mirror left-right first
                 for (int q = 0; q < (t & 3); ++q) { const int ny = xx, nx = -yy; yy = ny; xx = nx; }   // rot90 clockwise

@@ -44,6 +44,24 @@ int main(int argc, char** argv) {
     double ps = 0;
     for (int i = 0; i < 9; ++i) ps += p.v[i];
     printf("pvnet policy_sum %.6f value_sum %.6f\n", ps, v.v[0] + v.v[1]);
+    // Blokus Env shim: a random game through reset / possible_actions / step / get_player
+    {
+        az::Blokus& benv = az::Blokus::get();
+        az::Blokus::state_type bs = benv.reset();
+        bool bdone = false;
+        az::FloatTensor brew;
+        int bmoves = 0;
+        unsigned rng = 12345u;
+        while (!bdone) {
+            const auto acts = benv.possible_actions(bs, benv.get_player(bs));
+            if (bmoves == 0 && acts.size() != 58) { printf("blokus: %zu opening moves\n", acts.size()); return 1; }
+            rng = rng * 1664525u + 1013904223u;
+            std::tie(bs, brew, bdone) = benv.step(bs, acts[(rng >> 8) % acts.size()]);
+            ++bmoves;
+        }
+        printf("blokus game %d moves reward %g %g %g %g board %lld\n", bmoves, brew.v[0], brew.v[1], brew.v[2], brew.v[3],
+               (long long)benv.get_board(bs).numel());
+    }
     printf("shim ok\n");
     return 0;
 }

@@ -33,6 +33,8 @@ def test_mcts_pvnetwork_shims_play_a_game(nthreads):
         for ln in lines:
             assert 0.9 < float(ln[5]) < 1.0
         assert os.path.exists(os.path.join(d, "shim_0.pt.azw"))     # created like util.h:94-97
+        bl = [ln for ln in out.stdout.splitlines() if ln.startswith("blokus game")][0].split()
+        assert 40 <= int(bl[2]) <= 84 and int(bl[-1]) == 5 * 400                # the Blokus Env shim played a whole game
         pv = [ln for ln in out.stdout.splitlines() if ln.startswith("pvnet")][0].split()
         assert abs(float(pv[2]) - 1.0) < 1e-4 and abs(float(pv[4])) < 1e-5
 
