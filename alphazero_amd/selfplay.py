@@ -63,7 +63,7 @@ def gather_rows(cells, to_move, policy, reward, dst=0, device="cpu"):
     return None
 
 
-def run_selfplay(N, K, games_per_gpu, budget, Cs, blob_on_rank0, rounds, local_rank=0, seed=0, sink=None, contexts=2):
+def run_selfplay(N, K, games_per_gpu, budget, Cs, blob_on_rank0, rounds, local_rank=0, seed=0, sink=None, contexts=1):
     """Rank-sharded device self-play.  blob_on_rank0: weights on rank 0 (None
     elsewhere).  sink(cells, to_move, policy, reward) is called on rank 0 with
     the gathered rows.  Needs an MI355X per rank.
