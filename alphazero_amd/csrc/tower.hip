@@ -131,6 +131,82 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
     }
 }
 
+// The same stem as an fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products of fp32 weights and the u8 planes):
+// rows = 32 output channels, columns = 32 raster positions, K = CIN * 9 taken two at a time.  A wave takes every
+// fourth block of 32 positions and four row blocks (128 channels) at once; lane l carries position l & 31 and the
+// k half kh = l >> 5, i.e. im2col entry k = 2 t + kh of MFMA step t.  A lane's weights for a 128-channel slab stay
+// in registers across its position blocks; its im2col entries are single bytes of the board's planes in LDS.
+template <int PR, int CIN>
+__global__ void __launch_bounds__(256)
+az_stem_mfma_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out, float* __restrict__ out32,
+                    const float* __restrict__ w, const float* __restrict__ bias, int N, int C_pad, int Gd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((ext_vector_type(16))) float f32x16s;
+    constexpr int KW = CIN * 9, T = (KW + 1) / 2;
+    const int A = N * N, W = N + 1, P = W * W;
+    uint8_t* s_in = smem;                            // [CIN][A]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < CIN * A; i += 256) s_in[i] = planes[(size_t)b * CIN * A + i];
+    __syncthreads();
+    const int lane = tid & 63, wvi = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    for (int c0 = 0; c0 < C_pad; c0 += 128) {
+        float wr[4][T];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int k = 2 * t + kh;
+                wr[m][t] = k < KW ? w[(size_t)(c0 + 32 * m + l31) * KW + k] : 0.f;
+            }
+        for (int pb = wvi; pb * 32 < P; pb += 4) {
+            const int p = pb * 32 + l31;
+            const int y = p / W, x = p % W;
+            const bool cell = p < P && y < N && x < N;
+            unsigned vm = 0;                         // bit tap: the tap's source cell is on the board
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (cell && yy >= 0 && yy < N && xx >= 0 && xx < N) vm |= 1u << tap;
+            }
+            const int base = y * N + x;
+            f32x16s acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int k0 = 2 * t, k1 = 2 * t + 1;
+                const int tap0 = k0 % 9, tap1 = k1 % 9;
+                const int off0 = (k0 / 9) * A + (tap0 / 3 - 1) * N + (tap0 % 3 - 1);
+                const int off1 = (k1 / 9) * A + (tap1 / 3 - 1) * N + (tap1 % 3 - 1);
+                const bool ok = kh ? (k1 < KW && (vm >> tap1 & 1u)) : (vm >> tap0 & 1u) != 0;
+                const int src = ok ? base + (kh ? off1 : off0) : 0;
+                const float v = ok ? (float)s_in[src] : 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[m][t], v, acc[m], 0, 0, 0);
+            }
+            if (p < P) {
+                const size_t orow = ((size_t)(Gd + b * P + p)) * C_pad + c0 + 4 * kh;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bq = *(const float4*)(bias + c0 + 32 * m + 8 * q + 4 * kh);
+                        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (cell) o = make_float4(fmaxf(acc[m][4 * q] + bq.x, 0.f), fmaxf(acc[m][4 * q + 1] + bq.y, 0.f),
+                                                  fmaxf(acc[m][4 * q + 2] + bq.z, 0.f), fmaxf(acc[m][4 * q + 3] + bq.w, 0.f));
+                        uint2 pk;
+                        pk.x = (unsigned)Prec<PR>::to16(o.x) | ((unsigned)Prec<PR>::to16(o.y) << 16);
+                        pk.y = (unsigned)Prec<PR>::to16(o.z) | ((unsigned)Prec<PR>::to16(o.w) << 16);
+                        *(uint2*)(out + orow + 32 * m + 8 * q) = pk;
+                        *(float4*)(out32 + orow + 32 * m + 8 * q) = o;     // the residual stream stays fp32
+                    }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- conv 3x3
 // Per-layer implicit GEMMs (any C multiple of 128, any N <= 21): used where the fused kernel does not
 // apply (C = 256, or boards larger than one tile).  Shared pieces first.
@@ -1282,15 +1358,17 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 // BN(1) -> ReLU -> fc1 (N*N -> 64) -> ReLU -> fc2 (64 -> vd) -> softmax*2-1 (vd = 2 in the reference; a game
 // with more players asks for one entry per player).
 // hp layout (fp32): wp[c_out][C_pad], wv[C_pad], bp[c_out], bv (BN folded into wv/bv), then
-// fc1w [64][A], fc1b [64], fc2w [vd][64], fc2b [vd].  The logits pass through the output buffer.
+// fc1w [64][A], fc1b [64], fc2w [vd][64], fc2b [vd].
 template <int PR>
 __global__ void __launch_bounds__(256)
 az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const float* __restrict__ hp,
                 float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd, int c_out, int vd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int A = N * N, W = N + 1, P = W * W;
-    float* s_wp = (float*)smem;                      // [c_out][C_pad]
-    float* s_u = s_wp + c_out * C_pad;               // [A]
+    const int MR = (c_out + 1 + 31) / 32 * 32;       // policy channels, then the value channel, padded to MFMA row blocks
+    const int WS = C_pad + 4;                        // row stride of the weight image: ds_read_b128 of 32 rows without bank conflicts
+    float* s_wp = (float*)smem;                      // [MR][WS]
+    float* s_u = s_wp + MR * WS;                     // [A]
     float* s_red = s_u + A;                          // [256]
     float* s_f1 = s_red + 256;                       // [64]
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1302,61 +1380,89 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     const float* fc2w = fc1b + 64;
     const float* fc2b = fc2w + 64 * vd;
     float* pol = policy + (size_t)b * c_out * A;
-    for (int i = tid; i < c_out * C_pad; i += 256) s_wp[i] = hp[i];
-    __syncthreads();
-
-    // Both 1x1 convolutions.  Work items = (cell, group of <= 24 policy channels): an item holds 128 channels
-    // of its cell's row in registers and runs them against the group's weights (LDS, the same address for
-    // every lane: broadcast reads), so a 91-channel head keeps all 256 threads busy and reads a row four
-    // times, not 92.  The logits pass through the output buffer.
-    const int ncg = (c_out + 23) / 24, cgs = (c_out + ncg - 1) / ncg;
-    for (int item = tid; item < A * ncg; item += 256) {
-        const int a = item % A, cg = item / A;
-        const int y = a / N, xx = a % N;
-        const float* row = x + ((size_t)(Gd + b * P + y * W + xx)) * C_pad;
-        const int co0 = cg * cgs, co1 = min(c_out, co0 + cgs);
-        float sv = 0.f;
-        for (int ch0 = 0; ch0 < C_pad; ch0 += 128) {
-            float4 r[32];
-#pragma unroll
-            for (int q = 0; q < 32; ++q) r[q] = *(const float4*)(row + ch0 + 4 * q);
-            if (cg == 0) {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const float4 w4 = *(const float4*)(wvv + ch0 + 4 * q);
-                    sv += r[q].x * w4.x + r[q].y * w4.y + r[q].z * w4.z + r[q].w * w4.w;
-                }
-            }
-            for (int co = co0; co < co1; ++co) {
-                const float* wp = s_wp + co * C_pad + ch0;
-                float sp = 0.f;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const float4 w4 = *(const float4*)(wp + 4 * q);
-                    sp += r[q].x * w4.x + r[q].y * w4.y + r[q].z * w4.z + r[q].w * w4.w;
-                }
-                pol[co * A + a] = ch0 == 0 ? sp + bp[co] : pol[co * A + a] + sp;
-            }
-        }
-        if (cg == 0) s_u[a] = fmaxf(sv + bvv, 0.f);
+    for (int i = tid; i < MR * (C_pad / 4); i += 256) {          // wp rows and the wv row are contiguous in hp
+        const int r = i / (C_pad / 4), c4 = i % (C_pad / 4);
+        *(float4*)(s_wp + r * WS + 4 * c4) = r <= c_out ? *(const float4*)(hp + (size_t)r * C_pad + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    // softmax over the c_out * A entries
+
+    // Both 1x1 convolutions as one fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation):
+    // rows = output channels (policy, then value), columns = 32 cells of the board, K = C_pad.  A wave takes
+    // every fourth block of 32 cells.  Lane l carries cell l & 31 and the k half kh = l >> 5; MFMA step t of
+    // a 128-channel slab pairs kh with channel 64 kh + t, so a lane's 64 activations are one contiguous 256-byte
+    // run of its cell's fp32 row (16 x 16-byte loads, held in registers across the row blocks) and its weights
+    // four consecutive floats of one LDS row per read.  The logits pass through the output buffer.
+    // The softmax's maximum and sum are kept as this lane's running (max, sum of exp(logit - max)) over the logits it
+    // produces: the logits then cross the output buffer once (written here, rescaled in place below).
+    float run_m = -3.4e38f, run_s = 0.f;
+    {
+        typedef __attribute__((ext_vector_type(16))) float f32x16h;
+        const int lane = tid & 63, wvi = tid >> 6, l31h = lane & 31, kh = lane >> 5;
+        for (int cb = wvi; cb * 32 < A; cb += 4) {
+            const int a = cb * 32 + l31h, ac = min(a, A - 1);
+            const float* row = x + ((size_t)(Gd + b * P + (ac / N) * W + ac % N)) * C_pad + kh * 64;
+            for (int mb0 = 0; mb0 < MR / 32; mb0 += 3) {
+                f32x16h acc[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+                for (int ch0 = 0; ch0 < C_pad; ch0 += 128) {
+                    float4 xr[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) xr[q] = *(const float4*)(row + ch0 + 4 * q);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        if (mb0 + m >= MR / 32) continue;
+                        const float* wrow = s_wp + (32 * (mb0 + m) + l31h) * WS + ch0 + kh * 64;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float4 w4 = *(const float4*)(wrow + 4 * q);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, xr[q].x, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, xr[q].y, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, xr[q].z, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, xr[q].w, acc[m], 0, 0, 0);
+                        }
+                    }
+                }
+                if (a < A) {
+                    float bm = -3.4e38f;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = 32 * (mb0 + m) + 8 * (r >> 2) + 4 * kh + (r & 3);      // C/D layout of the 32x32 MFMAs
+                            if (co < c_out) { acc[m][r] += bp[co]; pol[co * A + a] = acc[m][r]; bm = fmaxf(bm, acc[m][r]); }
+                            else if (co == c_out) s_u[a] = fmaxf(acc[m][r] + bvv, 0.f);
+                        }
+                    const float nm = fmaxf(run_m, bm);
+                    float bs = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = 32 * (mb0 + m) + 8 * (r >> 2) + 4 * kh + (r & 3);
+                            if (co < c_out) bs += expf(acc[m][r] - nm);
+                        }
+                    run_s = run_s * expf(run_m - nm) + bs;
+                    run_m = nm;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // softmax over the c_out * A entries: combine the lanes' running pairs, then one pass over the logits
     const int n_pol = c_out * A;
-    float mx = -3.4e38f;
-    for (int i = tid; i < n_pol; i += 256) mx = fmaxf(mx, pol[i]);
-    s_red[tid] = mx;
+    s_red[tid] = run_m;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]); __syncthreads(); }
-    mx = s_red[0];
+    const float mx = s_red[0];
     __syncthreads();
-    float sum = 0.f;
-    for (int i = tid; i < n_pol; i += 256) { const float e = expf(pol[i] - mx); pol[i] = e; sum += e; }
-    s_red[tid] = sum;
+    s_red[tid] = run_s * expf(run_m - mx);           // a lane without logits: 0 * exp(-huge) = 0
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
-    sum = s_red[0];
-    for (int i = tid; i < n_pol; i += 256) pol[i] = pol[i] / sum;
+    const float inv = 1.f / s_red[0];
+    for (int i = tid; i < n_pol; i += 256) pol[i] = expf(pol[i] - mx) * inv;
     // value: fc1 with 4 threads per output
     {
         const int o = tid >> 2, part = tid & 3;
@@ -1394,7 +1500,7 @@ extern "C" size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows) {
 }
 
 extern "C" size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out) {
-    return ((size_t)c_out * C_pad + (size_t)N * N + 256 + 64) * 4;
+    return ((size_t)((c_out + 1 + 31) / 32 * 32) * (C_pad + 4) + (size_t)N * N + 256 + 64) * 4;
 }
 extern "C" size_t az_tower_stem_lds_bytes(int N, int C_pad, int c_in) {
     return (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
@@ -1420,6 +1526,15 @@ extern "C" int az_tower_configure(void) {
 
 extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
                                const float* bias, int B, int N, int C_pad, int Gd, int c_in) {
+    // the planes the two games here use run on the fp32 MFMA form; any other count on the generic kernel
+    if (c_in == 3 || c_in == 5) {
+        const size_t smm = (size_t)c_in * N * N + 16;
+#define STEM_MFMA(PR_, CIN_) hipLaunchKernelGGL((az_stem_mfma_kernel<PR_, CIN_>), dim3(B), dim3(256), smm, s, planes, out, out32, w, bias, N, C_pad, Gd)
+        if (prec == 1) { if (c_in == 3) STEM_MFMA(1, 3); else STEM_MFMA(1, 5); }
+        else { if (c_in == 3) STEM_MFMA(0, 3); else STEM_MFMA(0, 5); }
+#undef STEM_MFMA
+        return;
+    }
     const size_t sm = (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
     BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, w, bias, N, C_pad, Gd, c_in);
 }
