@@ -112,11 +112,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # AZ_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks: ranks share the devices
+    # there are and the collectives (a weight broadcast, a few scalars) run on host tensors
+    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
+    cdev = "cuda" if backend == "nccl" else "cpu"          # where the collectives' tensors live
     torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     N, K, G, budget = args.board, 5, args.games, args.budget
     Cs = synth.NETCONFIG2
@@ -130,10 +139,11 @@ def main():
     # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
     nw = eng.weights_size()
     if use_dist:
-        wt = torch.empty(nw, dtype=torch.float32, device="cuda")
+        wt = torch.empty(nw, dtype=torch.float32, device=cdev)
         if rank == 0:
             wt.copy_(torch.from_numpy(synth.make_blob(N, 3, Cs, 0)))
         dist.broadcast(wt, 0)
+        wt = wt.cuda()
         torch.cuda.synchronize()
         for e in engs:
             e.load_weights_dev(wt.data_ptr(), nw)
@@ -179,7 +189,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     prof = eng.profile_read()
@@ -189,7 +199,7 @@ def main():
     sims_local = st["sims_backed_up"] - sims0              # simulations this rank backed up inside the timed region
     tally = {k: st[k] - tally0[k] for k in TALLY}          # what this rank's tree kernel walked, read and wrote
     if use_dist:
-        t = torch.tensor([sims_local], dtype=torch.int64, device="cuda")
+        t = torch.tensor([sims_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         sims_all = int(t.item())
     else:
@@ -211,16 +221,16 @@ def main():
         st2 = {k: sum(x[k] for x in sts2) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts2) for k in sts2[0]}
         ng, nm, ns = st2["games"] - g0, st2["moves"] - m0, st2["sims_backed_up"] - s0fg
         if use_dist:                                       # whole-job totals
-            t = torch.tensor([ng, nm, ns], dtype=torch.int64, device="cuda")
+            t = torch.tensor([ng, nm, ns], dtype=torch.int64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             ng, nm, ns = int(t[0].item()), int(t[1].item()), int(t[2].item())
-            t = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el2], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
         games_info = {"seconds": el2, "games": ng, "moves": nm,
                       "games_per_hour": ng / el2 * 3600.0, "sims_per_s": ns / el2,
                       # finished games only: a lower bound on the rate while the first games are still running
-                      "moves_per_s": nm / el2, "mean_game_length": nm / max(1, ng),
+                      "moves_per_s": nm / el2, "mean_game_length": nm / ng if ng else None,
                       "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"],
                       "tree_restarts": st2["tree_restarts"]}
 
@@ -250,10 +260,10 @@ def main():
         el2 = time.perf_counter() - t1
         s1 = sum(e.stats()["sims_backed_up"] for e in engs) - s0
         if use_dist:
-            t = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el2], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
-            t = torch.tensor([s1], dtype=torch.int64, device="cuda")
+            t = torch.tensor([s1], dtype=torch.int64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             s1 = int(t.item())
         overlap = {"contexts_per_gpu": 2, "value": s1 / el2, "unit": "sims/s", "ms_per_step": el2 / args.steps * 1e3,
