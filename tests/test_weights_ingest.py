@@ -37,3 +37,26 @@ def test_pt2blob_matches_reference_checkpoint(tmp_path):
     assert (N, c_in, c_out, Cs) == (3, 3, 1, [128] * 10)
     assert np.array_equal(blob, ref)
     assert blob.size == synth.blob_size(3, 3, [128] * 10)
+
+
+def test_watch_converts_what_the_pointer_file_names(tmp_path):
+    """pt2blob --watch: a checkpoint named by the pointer file gets its twin once; a missing checkpoint, an
+    existing twin and an empty pointer file are left alone; relative paths resolve beside the pointer file."""
+    ptr = tmp_path / "ckpt_location.txt"
+    calls = []
+
+    def fake_convert(path):
+        calls.append(path)
+        open(path + ".azw", "wb").write(b"x")
+        return "ok"
+
+    assert pt2blob.watch_once(str(ptr), fake_convert) is None          # no pointer file yet
+    ptr.write_text("\n")
+    assert pt2blob.watch_once(str(ptr), fake_convert) is None          # empty
+    ptr.write_text("model_3.pt\n")
+    assert pt2blob.watch_once(str(ptr), fake_convert) is None          # named, not written yet
+    (tmp_path / "model_3.pt").write_bytes(b"pt")
+    assert pt2blob.watch_once(str(ptr), fake_convert) == "ok"
+    assert calls == [str(tmp_path / "model_3.pt")]
+    assert pt2blob.watch_once(str(ptr), fake_convert) is None          # twin exists now
+    assert len(calls) == 1

@@ -3,14 +3,21 @@
 util.h:108-139: a libtorch module archive) into the flat fp32 blob the HIP tower
 loads (`<path>.azw`, read by az/util.hpp and alphazero_amd.weights).
 
-    python tools/pt2blob.py model_12.pt [--board 15]
+    python tools/pt2blob.py model_12.pt
+    python tools/pt2blob.py --watch ckpt_location.txt      # beside an unmodified trainer
+
+With --watch it follows the trainer's pointer file (read under flock(LOCK_SH) like util.h:63-87) and
+writes the `.azw` twin of every checkpoint the file names, so that a generator whose load() found a
+`.pt` without its twin picks the new network up at its next load().
 
 Offline tool: libtorch/PyTorch is used here only, never on the hot path.
 """
 import argparse
+import fcntl
 import os
 import struct
 import sys
+import time
 
 import numpy as np
 
@@ -62,12 +69,57 @@ def read_azw(path):
     return N, c_in, c_out, Cs, blob
 
 
+def convert(checkpoint, out=None):
+    """<checkpoint> -> <checkpoint>.azw, written under a temporary name and renamed: a reader never sees half a file."""
+    N, c_in, c_out, Cs, blob = state_to_blob(load_state(checkpoint))
+    out = out or checkpoint + ".azw"
+    tmp = out + ".tmp%d" % os.getpid()
+    write_azw(tmp, N, c_in, c_out, Cs, blob)
+    os.replace(tmp, out)
+    return "wrote %s: N=%d c_in=%d c_out=%d Cs=%s floats=%d" % (out, N, c_in, c_out, Cs, blob.size)
+
+
+def read_pointer(pointer_file):
+    """The path the trainer's pointer file names (util.h:63-87: first line, shared lock), or None."""
+    try:
+        with open(pointer_file) as f:
+            fcntl.flock(f, fcntl.LOCK_SH)
+            try:
+                return f.readline().strip() or None
+            finally:
+                fcntl.flock(f, fcntl.LOCK_UN)
+    except OSError:
+        return None
+
+
+def watch_once(pointer_file, convert_fn=convert):
+    """One look at the pointer file: converts the named checkpoint if it exists and has no twin yet.
+    Relative paths are taken from the pointer file's directory (the trainer's working directory)."""
+    path = read_pointer(pointer_file)
+    if not path or path.endswith(".azw"):
+        return None
+    full = path if os.path.isabs(path) else os.path.join(os.path.dirname(os.path.abspath(pointer_file)), path)
+    if not os.path.exists(full) or os.path.exists(full + ".azw"):
+        return None
+    return convert_fn(full)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("checkpoint")
+    ap.add_argument("checkpoint", nargs="?")
     ap.add_argument("-o", "--out")
+    ap.add_argument("--watch", metavar="POINTER_FILE", help="follow this ckpt_location.txt and convert what it names")
+    ap.add_argument("--interval", type=float, default=1.0, help="seconds between looks at the pointer file")
     a = ap.parse_args()
-    N, c_in, c_out, Cs, blob = state_to_blob(load_state(a.checkpoint))
-    out = a.out or a.checkpoint + ".azw"
-    write_azw(out, N, c_in, c_out, Cs, blob)
-    print("wrote %s: N=%d c_in=%d c_out=%d Cs=%s floats=%d" % (out, N, c_in, c_out, Cs, blob.size))
+    if a.watch:
+        while True:
+            try:
+                msg = watch_once(a.watch)
+                if msg:
+                    print(msg, flush=True)
+            except Exception as e:  # noqa: BLE001 -- a checkpoint still being written: look again
+                print("pt2blob: %r, retrying" % (e,), flush=True)
+            time.sleep(a.interval)
+    if not a.checkpoint:
+        ap.error("a checkpoint or --watch is needed")
+    print(convert(a.checkpoint, a.out))
