@@ -32,6 +32,7 @@ EXPORTS = [
     "az_blokus_search_config", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
     "az_blokus_eval_hash", "az_blokus_eval_io", "az_blokus_search_result", "az_blokus_search_stats",
     "az_blokus_search_tower", "az_tower_shape",
+    "az_blokus_noise_device", "az_blokus_selfplay_config", "az_blokus_selfplay_moves", "az_blokus_replay_drain", "az_blokus_selfplay_stats",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
@@ -458,6 +459,46 @@ class Blokus:
         rd = C.c_int64()
         _chk(load().az_blokus_search_stats(self.h, C.byref(mn), C.byref(ms), C.byref(rs), C.byref(rd)))
         return dict(max_nodes=mn.value, max_slots=ms.value, restarts=rs.value, rounds=rd.value)
+
+    def noise_device(self, on=True):
+        _chk(load().az_blokus_noise_device(self.h, int(bool(on))))
+
+    # -- self-play -------------------------------------------------------------
+    def selfplay_config(self, ring_rows, max_budget):
+        """max_budget: the value given to search_config (entries kept per row)"""
+        self.K = int(max_budget)
+        _chk(load().az_blokus_selfplay_config(self.h, int(ring_rows)))
+
+    def selfplay_moves(self, budget, n_moves, tower_engine=None):
+        _chk(load().az_blokus_selfplay_moves(self.h, tower_engine.h if tower_engine is not None else None, int(budget), int(n_moves)))
+
+    def replay_drain(self, cap):
+        """finished rows, oldest first: planes u8 [n,5,20,20], to_move u8 [n], counts i32 [n], actions i32 / probs f32
+        [n,K] (the visited root children in action order; -1 / 0 beyond counts), reward f32 [n,4]"""
+        K = self.K
+        pl = np.empty((cap, self.PLANES, self.N, self.N), np.uint8)
+        tm = np.empty(cap, np.uint8)
+        cnt = np.empty(cap, np.int32)
+        act = np.empty((cap, K), np.int32)
+        pr = np.empty((cap, K), np.float32)
+        rw = np.empty((cap, 4), np.float32)
+        n = C.c_int32()
+        _chk(load().az_blokus_replay_drain(self.h, int(cap), _ptr(pl), _ptr(tm), _ptr(cnt), _ptr(act), _ptr(pr), _ptr(rw), C.byref(n)))
+        n = n.value
+        return dict(planes=pl[:n], to_move=tm[:n], counts=cnt[:n], actions=act[:n], probs=pr[:n], reward=rw[:n])
+
+    @staticmethod
+    def dense_policy(actions, probs, counts):
+        """the rows' policies in the Env's action shape [n, 91, 20, 20]"""
+        out = np.zeros((len(counts), Blokus.ACTIONS), np.float32)
+        for r, c in enumerate(counts):
+            out[r, actions[r, :c]] = probs[r, :c]
+        return out.reshape(-1, Blokus.ORIENTS, Blokus.N, Blokus.N)
+
+    def selfplay_stats(self):
+        mv, gm, rw, dr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(load().az_blokus_selfplay_stats(self.h, C.byref(mv), C.byref(gm), C.byref(rw), C.byref(dr)))
+        return dict(moves=mv.value, games=gm.value, rows=rw.value, dropped=dr.value)
 
     def sync(self):
         _chk(load().az_blokus_sync(self.h))

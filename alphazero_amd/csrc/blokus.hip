@@ -18,6 +18,7 @@
 #include "az_dev.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <mutex>
 #include <string>
@@ -69,7 +70,29 @@ struct AzbDev {
     float*    value;        // [G][4]
     float*    noise;        // [G][AZB_NOISE_CAP]
     int*      restarts;     // [G] searches restarted because the arena was full
+    int*      search_restarts;  // [G] ... in the current search
+    int*      truncated;    // [G] searches ended early because the arena filled up a second time
+    unsigned* noise_ctr;    // [G] device-noise draws so far (use_noise == 2)
+    // ---- self-play state, allocated by az_blokus_selfplay_config ----
+    int sp_k;               // policy entries kept per row = max_budget (a root child needs a visit to have one)
+    int ring_cap;           // rows of the replay ring
+    float*     sp_avg_len;      // [G] running mean game length (generate.cpp:25-29,69)
+    long long* sp_game_count;   // [G]
+    unsigned*  sp_sample_ctr;   // [G]
+    uint8_t*   row_planes;      // [G][84][5*400] rows of the game in progress (buffer.temporary_append, generate.cpp:85)
+    uint8_t*   row_tomove;      // [G][84]
+    int*       row_cnt;         // [G][84] policy entries of the row
+    uint16_t*  row_act;         // [G][84][sp_k] their actions, ascending
+    float*     row_p;           // [G][84][sp_k] n_child / n_root
+    uint8_t*   ring_planes;     // [ring_cap][5*400] rows of finished games (buffer.send_reward, generate.cpp:110)
+    uint8_t*   ring_tomove;
+    int*       ring_cnt;
+    uint16_t*  ring_act;
+    float*     ring_p;
+    float*     ring_reward;     // [ring_cap][4] by absolute player
+    unsigned long long* sp_counters;    // 0 rows in the ring, 1 rows dropped (ring full), 2 moves played, 3 games finished
 };
+#define AZB_MAX_MOVES 84                                // 4 players x 21 pieces
 #define AZB_PATH_CAP 88                                 // a game has at most 84 pieces
 #define AZB_NOISE_CAP 4096
 
@@ -254,17 +277,27 @@ __device__ void azb_load(const AzbDev& d, int g, uint32_t* s_own, uint32_t* s_us
 }
 
 // Env::reset for every game, including the first player's legal set.
-extern "C" __global__ void __launch_bounds__(64) azb_reset_kernel(AzbDev d) {
-    AZB_SMEM_DECL;
-    (void)s_last; (void)s_meta;
-    const int g = blockIdx.x, lane = threadIdx.x;
-    for (int i = lane; i < 4 * AZB_N; i += 64) { s_own[i] = 0u; d.own[(size_t)g * 4 * AZB_N + i] = 0u; }
-    if (lane < 4) { s_used[lane] = 0u; d.used[g * 4 + lane] = 0u; d.last_piece[g * 4 + lane] = 0xFF; d.final_reward[g * 4 + lane] = 0.f; }
+__device__ void azb_reset_game(const AzbDev& d, int g, uint32_t* s_own, uint32_t* s_used, uint2* s_rows, const uint2* s_tab,
+                               uint32_t* s_bits, int* s_cnt, bool keep_reward) {
+    const int lane = threadIdx.x;
     __syncthreads();
-    azb_load_table(s_tab);
+    for (int i = lane; i < 4 * AZB_N; i += 64) { s_own[i] = 0u; d.own[(size_t)g * 4 * AZB_N + i] = 0u; }
+    if (lane < 4) {
+        s_used[lane] = 0u; d.used[g * 4 + lane] = 0u; d.last_piece[g * 4 + lane] = 0xFF;
+        if (!keep_reward) d.final_reward[g * 4 + lane] = 0.f;
+    }
+    __syncthreads();
     const int cnt = azb_scan(s_own, 0u, 0, s_rows, s_tab, s_bits, s_cnt);
     for (int i = lane; i < AZB_SET_WORDS; i += 64) d.legal_bits[(size_t)g * AZB_SET_WORDS + i] = s_bits[i];
     if (lane == 0) { d.to_move[g] = 0; d.over[g] = 0; d.moves[g] = 0; d.legal_count[g] = cnt; }
+    __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(64) azb_reset_kernel(AzbDev d) {
+    AZB_SMEM_DECL;
+    (void)s_last; (void)s_meta;
+    azb_load_table(s_tab);
+    azb_reset_game(d, blockIdx.x, s_own, s_used, s_rows, s_tab, s_bits, s_cnt, false);
 }
 
 // Env::step, batched: actions[g] = o*400 + y*20 + x, or -1 to leave game g alone.
@@ -351,14 +384,35 @@ __device__ void azb_unpack_reward(int code, float r[4]) {
     for (int q = 0; q < 4; ++q) { const int c = code >> (2 * q) & 3; r[q] = c == 1 ? 1.f : (c == 2 ? -1.f : 0.f); }
 }
 
-__device__ void azb_write_planes(const AzbDev& d, int g, const uint32_t* s_own, int to_move) {
-    uint8_t* pl = d.leaf_planes + (size_t)g * AZB_PLANES * AZB_CELLS;
+__device__ void azb_planes_to(uint8_t* pl, const uint32_t* s_own, int to_move) {
     for (int i = threadIdx.x; i < AZB_CELLS; i += 64) {
         const int y = i / AZB_N, x = i - AZB_N * y;
 #pragma unroll
         for (int p = 0; p < 4; ++p) pl[p * AZB_CELLS + i] = s_own[p * AZB_N + y] >> x & 1u;
         pl[4 * AZB_CELLS + i] = (uint8_t)to_move;
     }
+}
+__device__ void azb_write_planes(const AzbDev& d, int g, const uint32_t* s_own, int to_move) {
+    azb_planes_to(d.leaf_planes + (size_t)g * AZB_PLANES * AZB_CELLS, s_own, to_move);
+}
+
+// dirichlet(n_actions, alpha = 0.05) of util.h:42-58 drawn on the device for the root being expanded
+__device__ void azb_device_noise(const AzbDev& d, int g, int count) {
+    float* nz = d.noise + (size_t)g * AZB_NOISE_CAP;
+    const unsigned ctr = d.noise_ctr[g];
+    const unsigned stream = 0x80000000u | (unsigned)(d.slot_base + g);
+    const int n = count < AZB_NOISE_CAP ? count : AZB_NOISE_CAP;
+    double part = 0.0;
+    for (int k = threadIdx.x; k < n; k += 64) {
+        const float x = az_gamma_draw(d.seed, stream, (ctr * (unsigned)AZB_NOISE_CAP + (unsigned)k) * 32u, 0.05f);
+        nz[k] = x;
+        part += (double)x;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 64) nz[k] = part > 0.0 ? (float)((double)nz[k] / part) : 1.0f / (float)n;
+    if (threadIdx.x == 0) d.noise_ctr[g] = ctr + 1u;
+    __syncthreads();
 }
 
 // Consume the evaluation of the previous round: expand (+ noise at the root) and back up.
@@ -374,12 +428,28 @@ __device__ void azb_tree_apply(const AzbDev& d, int g) {
         const int cnt = azb_uni(d.leaf_count[g]);
         const int hdr = azb_uni(d.n_slots[g]);
         if (hdr + 1 + cnt > d.edge_cap) {
-            // arena full: drop the tree and search the position again from a fresh root (mcts.hpp:392-414)
-            if (lane == 0) { d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; d.sims_done[g] = 0; d.pending[g] = AZ_PEND_NONE; d.restarts[g] += 1; }
+            // Arena full.  The first time in a search: drop the tree and search the position again from a fresh root
+            // (mcts.hpp:392-414).  If it fills up again the position is too wide for the arena at this budget: take
+            // the virtual loss of the unfinished descent back and end the search with the simulations it has.
+            if (azb_uni(d.search_restarts[g]) == 0 && pend != AZ_PEND_ROOT) {
+                if (lane == 0) {
+                    d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; d.sims_done[g] = 0; d.pending[g] = AZ_PEND_NONE;
+                    d.restarts[g] += 1; d.search_restarts[g] = 1;
+                }
+            } else {
+                const float vl = d.vl;
+                for (int t = lane; t < plen; t += 64) {
+                    AzEdge* e = &E[path[t]];
+                    e->n = (int)((float)e->n - vl);
+                    e->v = e->v + vl;
+                }
+                if (lane == 0) { d.sims_target[g] = d.sims_done[g]; d.pending[g] = AZ_PEND_NONE; d.truncated[g] += 1; }
+            }
             __syncthreads();
             return;
         }
         const bool is_root = pend == AZ_PEND_ROOT;
+        if (is_root && d.use_noise == 2) azb_device_noise(d, g, cnt);
         const float* pol = d.policy + (size_t)g * AZB_ACTIONS;
         const float* nz = d.noise + (size_t)g * AZB_NOISE_CAP;
         const uint32_t* bits = d.leaf_bits + (size_t)g * AZB_SET_WORDS;
@@ -526,7 +596,7 @@ extern "C" __global__ void azb_search_begin_kernel(AzbDev d, int budget) {
     if (g >= d.G) return;
     d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0;
     d.sims_done[g] = 0; d.sims_target[g] = budget > 1 ? budget : 1;     // the loop body runs once even for budget <= 0
-    d.pending[g] = AZ_PEND_NONE; d.path_len[g] = 0;
+    d.pending[g] = AZ_PEND_NONE; d.path_len[g] = 0; d.search_restarts[g] = 0;
     d.t_status[g] = d.over[g] ? AZ_ST_IDLE : AZ_ST_RUN;
 }
 
@@ -559,6 +629,116 @@ extern "C" __global__ void __launch_bounds__(256) azb_eval_hash_kernel(const uin
         const int t = (int)((az_splitmix64(H ^ (0xABCDEFull + (unsigned long long)tid)) >> 40) & 0xFFFFull);
         value[4 * g + tid] = __fdiv_rn((float)t - 32768.0f, 40000.0f);
     }
+}
+
+// ----------------------------------------------------------------------------------------------- self-play
+// The body of generate.cpp's move loop (:82-118) for one game whose search just finished: record the row
+// (board planes + the search's policy), choose the move (sampled in proportion to the visits while the move
+// number is below a fifth of the running mean game length, the first arg-max afterwards), play it, and at the
+// end of the game hand the rows to the ring with the final reward and start the next game.  The policy of a
+// row is kept sparse: (action, n_child / n_root) for the root's visited children in action order -- a dense
+// [91,20,20] row is 146 KB of mostly zeros; a search of `budget` simulations visits at most `budget` children.
+extern "C" __global__ void __launch_bounds__(64) azb_selfplay_move_kernel(AzbDev d) {
+    AZB_SMEM_DECL;
+    __shared__ int s_pick;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (azb_uni(d.t_status[g]) == AZ_ST_RUN || azb_uni(d.n_nodes[g]) == 0 || azb_uni(d.over[g])) return;
+    azb_load_table(s_tab);
+    azb_load(d, g, s_own, s_used, s_last, s_meta);
+    const AzEdge* E = d.edges + (size_t)g * d.edge_cap;
+    const uint16_t* EA = d.eact + (size_t)g * d.edge_cap;
+    const int cnt = azb_uni(E[0].n);                                    // the root's children: slots 1 .. cnt
+    const float rn = (float)azb_uni(d.root_n[g]);
+    const int i = s_meta[2] + 1;                                        // generate.cpp:82, 1-based
+    const int K = d.sp_k;
+    const size_t row = (size_t)g * AZB_MAX_MOVES + (i - 1);
+    azb_planes_to(d.row_planes + row * (AZB_PLANES * AZB_CELLS), s_own, s_meta[0]);
+    {
+        uint16_t* ra = d.row_act + row * K;
+        float* rp = d.row_p + row * K;
+        int base = 0;
+        for (int c = 0; c < cnt; c += 64) {
+            const int k = c + lane;
+            const int n = k < cnt ? E[1 + k].n : 0;
+            const unsigned long long m = __ballot(n > 0);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (n > 0 && pos < K) { ra[pos] = EA[1 + k]; rp[pos] = __fdiv_rn((float)n, rn); }     // mcts.hpp:136-146
+            base += __popcll(m);
+        }
+        if (lane == 0) { d.row_cnt[row] = base < K ? base : K; d.row_tomove[row] = (uint8_t)s_meta[0]; }
+    }
+    int chosen = -1;
+    if ((double)i < (double)d.sp_avg_len[g] * 0.2) {                   // generate.cpp:88: sample ~ visits
+        unsigned part = 0;
+        for (int k = lane; k < cnt; k += 64) part += (unsigned)E[1 + k].n;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        unsigned r[4];
+        const unsigned ctr = d.sp_sample_ctr[g];
+        az_philox4(d.seed ^ 0x53414D50ull, (unsigned)(d.slot_base + g), ctr, r);
+        const unsigned pick = (unsigned)(((unsigned long long)r[0] * part) >> 32);
+        unsigned carry = 0;
+        for (int c = 0; c < cnt && chosen < 0; c += 64) {
+            const int k = c + lane;
+            unsigned x = k < cnt ? (unsigned)E[1 + k].n : 0u;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            const unsigned long long m = __ballot(k < cnt && carry + x > pick);
+            if (m) chosen = c + (__ffsll((long long)m) - 1);
+            carry += __shfl(x, 63, 64);
+        }
+        if (lane == 0) d.sp_sample_ctr[g] = ctr + 1u;
+    } else {                                                            // generate.cpp:95: first arg-max
+        int bn = -1, bk = -1;
+        for (int k = lane; k < cnt; k += 64) { const int n = E[1 + k].n; if (n > bn) { bn = n; bk = k; } }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int on = __shfl_xor(bn, o, 64), ok = __shfl_xor(bk, o, 64);
+            if (ok >= 0 && (bk < 0 || on > bn || (on == bn && ok < bk))) { bn = on; bk = ok; }
+        }
+        chosen = bk;
+    }
+    chosen = azb_uni(chosen);
+    if (chosen < 0) chosen = 0;                                         // no visit anywhere: cannot happen once a search ran
+    if (lane == 0) { s_pick = EA[1 + chosen]; atomicAdd(&d.sp_counters[2], 1ull); }
+    __syncthreads();
+    azb_play(d, g, s_pick, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta, nullptr, nullptr);   // generate.cpp:103
+    if (!s_meta[1]) return;
+    // game over: buffer.send_reward(reward), stats, env.reset() (generate.cpp:110-118,75)
+    int base = -1;
+    if (lane == 0) {
+        unsigned long long old = atomicAdd(&d.sp_counters[0], 0ull);
+        for (;;) {
+            if (old + (unsigned long long)i > (unsigned long long)d.ring_cap) { atomicAdd(&d.sp_counters[1], (unsigned long long)i); break; }
+            const unsigned long long prev = atomicCAS(&d.sp_counters[0], old, old + (unsigned long long)i);
+            if (prev == old) { base = (int)old; break; }
+            old = prev;
+        }
+    }
+    base = __shfl(base, 0, 64);
+    if (base >= 0)
+        for (int r = 0; r < i; ++r) {
+            const size_t src = (size_t)g * AZB_MAX_MOVES + r, dst = (size_t)base + r;
+            const uint32_t* sp = (const uint32_t*)(d.row_planes + src * (AZB_PLANES * AZB_CELLS));
+            uint32_t* dp = (uint32_t*)(d.ring_planes + dst * (AZB_PLANES * AZB_CELLS));
+            for (int c = lane; c < AZB_PLANES * AZB_CELLS / 4; c += 64) dp[c] = sp[c];
+            const int n = d.row_cnt[src];
+            for (int c = lane; c < n; c += 64) { d.ring_act[dst * K + c] = d.row_act[src * K + c]; d.ring_p[dst * K + c] = d.row_p[src * K + c]; }
+            if (lane == 0) { d.ring_cnt[dst] = n; d.ring_tomove[dst] = d.row_tomove[src]; }
+            if (lane < 4) d.ring_reward[dst * 4 + lane] = d.final_reward[g * 4 + lane];
+        }
+    if (lane == 0) {
+        const long long gc = d.sp_game_count[g] + 1;                    // generate.cpp:25-29
+        d.sp_game_count[g] = gc;
+        const float al = d.sp_avg_len[g];
+        d.sp_avg_len[g] = al + ((float)i - al) / (float)gc;
+        atomicAdd(&d.sp_counters[3], 1ull);
+    }
+    azb_reset_game(d, g, s_own, s_used, s_rows, s_tab, s_bits, s_cnt, true);
+}
+
+extern "C" __global__ void azb_selfplay_init_kernel(AzbDev d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    d.sp_avg_len[g] = 25.f;                                             // generate.cpp:69
+    d.sp_game_count[g] = 0; d.sp_sample_ctr[g] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -723,7 +903,7 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
     BHIP(hipSetDevice(b->device));
     const int G = b->d.G;
     b->d.vl = vl; b->d.c_puct_i = (int)c_puct;                        // Node::ucb takes int (node.hpp:47)
-    b->d.edge_cap = edge_cap > 0 ? edge_cap : (max_budget + 2) * 768;   // ~510 slots per node observed at 2048 games x 400 sims
+    b->d.edge_cap = edge_cap > 0 ? edge_cap : (max_budget + 2) * 1024;  // ~510 slots per node observed at 2048 games x 400 sims, 660+ at single roots
     b->max_budget = max_budget;
     int rc = AZ_OK;
 #define BA(ptr, n) do { if (rc == AZ_OK) rc = balloc(b, &(ptr), (size_t)(n)); } while (0)
@@ -732,7 +912,8 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
     BA(b->d.pending, G); BA(b->d.path_len, G); BA(b->d.path, (size_t)G * AZB_PATH_CAP); BA(b->d.path_owner, (size_t)G * AZB_PATH_CAP);
     BA(b->d.pend_result, (size_t)G * 4); BA(b->d.leaf_bits, (size_t)G * AZB_SET_WORDS); BA(b->d.leaf_count, G); BA(b->d.leaf_player, G);
     BA(b->d.leaf_planes, (size_t)G * AZB_PLANES * AZB_CELLS); BA(b->d.policy, (size_t)G * AZB_ACTIONS); BA(b->d.value, (size_t)G * 4);
-    BA(b->d.noise, (size_t)G * AZB_NOISE_CAP); BA(b->d.restarts, G);
+    BA(b->d.noise, (size_t)G * AZB_NOISE_CAP); BA(b->d.restarts, G); BA(b->d.noise_ctr, G);
+    BA(b->d.search_restarts, G); BA(b->d.truncated, G);
 #undef BA
     if (rc != AZ_OK) { b->d.edges = nullptr; return rc; }
     BHIP(hipDeviceSynchronize());            // the zero fills ran on the null stream, the context's stream does not wait for it
@@ -749,6 +930,17 @@ extern "C" int az_blokus_set_noise(az_blokus* b, const float* noise, int n) {
     if (n < 1 || n > AZB_NOISE_CAP) return bfail(AZ_E_ARG, "noise length out of range (1..4096)");
     BHIP(hipMemcpy2D(b->d.noise, sizeof(float) * AZB_NOISE_CAP, noise, sizeof(float) * n, sizeof(float) * n, b->d.G, hipMemcpyHostToDevice));
     b->d.use_noise = 1;
+    return AZ_OK;
+}
+
+// The same noise drawn on the device (gamma(0.05) draws per legal action of every fresh root, normalised: util.h:42-58),
+// a fresh draw per search; on = 0 switches noise off.
+extern "C" int az_blokus_noise_device(az_blokus* b, int on) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipStreamSynchronize(b->stream));
+    b->d.use_noise = on ? 2 : 0;
     return AZ_OK;
 }
 
@@ -887,16 +1079,123 @@ extern "C" int az_blokus_search_stats(az_blokus* b, int32_t* max_nodes, int32_t*
     BHIP(hipSetDevice(b->device));
     BHIP(hipStreamSynchronize(b->stream));
     const int G = b->d.G;
-    std::vector<int> a((size_t)G), s((size_t)G), r((size_t)G);
+    std::vector<int> a((size_t)G), s((size_t)G), r((size_t)G), t((size_t)G);
     BHIP(hipMemcpy(a.data(), b->d.n_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
     BHIP(hipMemcpy(s.data(), b->d.n_slots, sizeof(int) * G, hipMemcpyDeviceToHost));
     BHIP(hipMemcpy(r.data(), b->d.restarts, sizeof(int) * G, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(t.data(), b->d.truncated, sizeof(int) * G, hipMemcpyDeviceToHost));
     int mn = 0, ms = 0, rs = 0;
-    for (int g = 0; g < G; ++g) { mn = a[g] > mn ? a[g] : mn; ms = s[g] > ms ? s[g] : ms; rs += r[g]; }
+    for (int g = 0; g < G; ++g) { mn = a[g] > mn ? a[g] : mn; ms = s[g] > ms ? s[g] : ms; rs += r[g] + t[g]; }
     if (max_nodes) *max_nodes = mn;
     if (max_slots) *max_slots = ms;
     if (restarts) *restarts = rs;
     if (rounds) *rounds = b->rounds;
+    return AZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------- self-play, host side
+// generate.cpp:37-123 for the G games: az_blokus_selfplay_config allocates the per-game row buffers and a ring
+// of `ring_rows` finished rows; az_blokus_selfplay_moves plays `n_moves` moves of every game (a search of
+// `budget` simulations from a fresh root, then the move), starting the next game wherever one ends;
+// az_blokus_replay_drain hands the finished rows over.
+extern "C" int az_blokus_selfplay_config(az_blokus* b, int ring_rows) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    if (b->d.sp_counters) return bfail(AZ_E_STATE, "self-play is already configured");
+    if (ring_rows < AZB_MAX_MOVES) return bfail(AZ_E_ARG, "ring_rows must hold at least one game (84 rows)");
+    BHIP(hipSetDevice(b->device));
+    const int G = b->d.G, K = b->max_budget;
+    const size_t rows = (size_t)G * AZB_MAX_MOVES, R = (size_t)ring_rows;
+    b->d.sp_k = K; b->d.ring_cap = ring_rows;
+    int rc = AZ_OK;
+#define BA(ptr, n) do { if (rc == AZ_OK) rc = balloc(b, &(ptr), (size_t)(n)); } while (0)
+    BA(b->d.sp_avg_len, G); BA(b->d.sp_game_count, G); BA(b->d.sp_sample_ctr, G);
+    BA(b->d.row_planes, rows * AZB_PLANES * AZB_CELLS); BA(b->d.row_tomove, rows); BA(b->d.row_cnt, rows);
+    BA(b->d.row_act, rows * K); BA(b->d.row_p, rows * K);
+    BA(b->d.ring_planes, R * AZB_PLANES * AZB_CELLS); BA(b->d.ring_tomove, R); BA(b->d.ring_cnt, R);
+    BA(b->d.ring_act, R * K); BA(b->d.ring_p, R * K); BA(b->d.ring_reward, R * 4);
+    BA(b->d.sp_counters, 8);
+#undef BA
+    if (rc != AZ_OK) { b->d.sp_counters = nullptr; return rc; }
+    BHIP(hipDeviceSynchronize());            // the zero fills ran on the null stream
+    hipLaunchKernelGGL(azb_selfplay_init_kernel, dim3((G + 63) / 64), dim3(64), 0, b->stream, b->d);
+    BHIP(hipGetLastError());
+    return AZ_OK;
+}
+
+// tower = NULL: the integer-hash evaluator
+extern "C" int az_blokus_selfplay_moves(az_blokus* b, az_ctx* tower, int budget, int n_moves) {
+    BNEED(b);
+    if (!b->d.sp_counters) return bfail(AZ_E_STATE, "az_blokus_selfplay_config has not been called");
+    if (n_moves < 0) return bfail(AZ_E_ARG, "n_moves is negative");
+    for (int m = 0; m < n_moves; ++m) {
+        AZB_CHK(tower ? az_blokus_search_tower(b, tower, budget) : az_blokus_search(b, budget));
+        hipLaunchKernelGGL(azb_selfplay_move_kernel, dim3(b->d.G), dim3(64), 0, b->stream, b->d);
+        BHIP(hipGetLastError());
+    }
+    return AZ_OK;
+}
+
+// Up to `cap` finished rows, oldest first, removed from the ring: planes u8 [cap][5*400], to_move u8 [cap],
+// counts i32 [cap] policy entries per row, actions i32 / probs f32 [cap][K] (K = max_budget; entry j < counts[r]:
+// policy[actions] = probs, every other entry of the [91,20,20] policy is zero), reward f32 [cap][4] by absolute
+// player.  Returns the number of rows through *n_rows.
+extern "C" int az_blokus_replay_drain(az_blokus* b, int cap, uint8_t* planes, uint8_t* to_move, int32_t* counts,
+                                      int32_t* actions, float* probs, float* reward, int32_t* n_rows) {
+    BNEED(b); BNEED(n_rows);
+    *n_rows = 0;
+    if (!b->d.sp_counters) return bfail(AZ_E_STATE, "az_blokus_selfplay_config has not been called");
+    if (cap < 0) return bfail(AZ_E_ARG, "cap is negative");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipStreamSynchronize(b->stream));
+    unsigned long long cnt = 0;
+    BHIP(hipMemcpy(&cnt, b->d.sp_counters, 8, hipMemcpyDeviceToHost));
+    const size_t n = (size_t)std::min<unsigned long long>(cnt, (unsigned long long)cap), K = (size_t)b->d.sp_k;
+    const size_t PB = AZB_PLANES * AZB_CELLS;
+    if (n == 0) return AZ_OK;
+    BNEED(planes); BNEED(to_move); BNEED(counts); BNEED(actions); BNEED(probs); BNEED(reward);
+    std::vector<uint16_t> act16(n * K);
+    BHIP(hipMemcpy(planes, b->d.ring_planes, n * PB, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(to_move, b->d.ring_tomove, n, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(counts, b->d.ring_cnt, n * 4, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(act16.data(), b->d.ring_act, n * K * 2, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(probs, b->d.ring_p, n * K * 4, hipMemcpyDeviceToHost));
+    BHIP(hipMemcpy(reward, b->d.ring_reward, n * 16, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < n; ++r)
+        for (size_t j = 0; j < K; ++j) {
+            const bool live = (int)j < counts[r];
+            actions[r * K + j] = live ? act16[r * K + j] : -1;
+            if (!live) probs[r * K + j] = 0.f;
+        }
+    const size_t rest = (size_t)cnt - n;
+    // keep the tail: shift it to the front, n rows at a time from the low end (source and destination of one copy never overlap)
+    for (size_t off = 0; off < rest; off += n) {
+        const size_t k = std::min(n, rest - off);
+        BHIP(hipMemcpy(b->d.ring_planes + off * PB, b->d.ring_planes + (off + n) * PB, k * PB, hipMemcpyDeviceToDevice));
+        BHIP(hipMemcpy(b->d.ring_tomove + off, b->d.ring_tomove + off + n, k, hipMemcpyDeviceToDevice));
+        BHIP(hipMemcpy(b->d.ring_cnt + off, b->d.ring_cnt + off + n, k * 4, hipMemcpyDeviceToDevice));
+        BHIP(hipMemcpy(b->d.ring_act + off * K, b->d.ring_act + (off + n) * K, k * K * 2, hipMemcpyDeviceToDevice));
+        BHIP(hipMemcpy(b->d.ring_p + off * K, b->d.ring_p + (off + n) * K, k * K * 4, hipMemcpyDeviceToDevice));
+        BHIP(hipMemcpy(b->d.ring_reward + off * 4, b->d.ring_reward + (off + n) * 4, k * 16, hipMemcpyDeviceToDevice));
+    }
+    const unsigned long long left = rest;
+    BHIP(hipMemcpy(b->d.sp_counters, &left, 8, hipMemcpyHostToDevice));
+    *n_rows = (int)n;
+    return AZ_OK;
+}
+
+// moves played, games finished, rows waiting in the ring, rows dropped because the ring was full
+extern "C" int az_blokus_selfplay_stats(az_blokus* b, int64_t* moves, int64_t* games, int64_t* rows, int64_t* dropped) {
+    BNEED(b);
+    if (!b->d.sp_counters) return bfail(AZ_E_STATE, "az_blokus_selfplay_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipStreamSynchronize(b->stream));
+    unsigned long long k[4];
+    BHIP(hipMemcpy(k, b->d.sp_counters, sizeof k, hipMemcpyDeviceToHost));
+    if (rows) *rows = (int64_t)k[0];
+    if (dropped) *dropped = (int64_t)k[1];
+    if (moves) *moves = (int64_t)k[2];
+    if (games) *games = (int64_t)k[3];
     return AZ_OK;
 }
 

@@ -73,31 +73,7 @@ __device__ void az_write_planes(const AzTreeDev& d, int slot, const uint8_t* s_c
 }
 
 // ------------------------------------------------------- Dirichlet on device
-// util.h:42-58: gamma(alpha) draws, double sum, divide.  Marsaglia-Tsang with
-// the alpha+1 boost (the algorithm std::gamma_distribution uses); counter-based
-// uniforms.  Only the distribution is defined by the reference (random_device).
-__device__ float az_gamma_draw(unsigned long long seed, unsigned stream, unsigned base, float alpha) {
-    const float a1 = alpha + 1.0f;
-    const float dd = a1 - 1.0f / 3.0f;
-    const float cc = 1.0f / sqrtf(9.0f * dd);
-    float gv = dd;
-    unsigned r[4];
-    for (int it = 0; it < 16; ++it) {
-        az_philox4(seed, stream, base + (unsigned)it, r);
-        const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u3 = ((float)(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float x = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
-        float v = 1.0f + cc * x;
-        if (v <= 0.0f) continue;
-        v = v * v * v;
-        if (logf(u3) < 0.5f * x * x + dd - dd * v + dd * logf(v)) { gv = dd * v; break; }
-    }
-    az_philox4(seed, stream, base + 16u, r);
-    const float u4 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return gv * powf(u4, 1.0f / alpha);
-}
-
+// util.h:42-58: gamma(alpha) draws (az_gamma_draw, az_dev.h), double sum, divide.
 __device__ void az_device_noise(const AzTreeDev& d, int g, int count) {
     float* nz = d.noise + (size_t)g * d.A;
     const unsigned ctr = d.noise_ctr[g];

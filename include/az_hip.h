@@ -250,8 +250,9 @@ void* az_blokus_stream(az_blokus*);
  * reference's search arithmetic on four players and an irregular action set -- an edge is valued for the
  * player who chooses it (result[parent->player], mcts.hpp:336, with four entries), a node carries its own
  * child count, children are in action order, ties go to the first child.  Every search starts from a fresh
- * root; a tree that outgrows its arena (edge_cap slots per game, 0 = (max_budget + 2) * 768) is dropped and
- * searched again.  az_blokus_search runs `budget` simulations per game with the integer-hash evaluator
+ * root; a tree that outgrows its arena (edge_cap slots per game, 0 = (max_budget + 2) * 1024) is dropped and
+ * searched again, and if it outgrows it a second time the search ends with the simulations it has (both counted
+ * by az_blokus_search_stats' restarts).  az_blokus_search runs `budget` simulations per game with the integer-hash evaluator
  * (bit-reproducible on the CPU); begin / round / eval_io let an evaluator outside the library take the hash
  * evaluator's place: after a round its input planes are in *planes_dev, before the next round its outputs
  * must be in *policy_dev / *value_dev (softmax over all 91*400 actions, value per player). */
@@ -270,6 +271,25 @@ int az_blokus_eval_io(az_blokus*, uint8_t** planes_dev, float** policy_dev, floa
 int az_blokus_search_result(az_blokus*, int game, int cap, int32_t* n_children, int32_t* root_n,
                             int32_t* actions, int32_t* n, float* v, float* p);
 int az_blokus_search_stats(az_blokus*, int32_t* max_nodes, int32_t* max_slots, int32_t* restarts, int64_t* rounds);
+/* dirichlet(n_actions, 0.05) of util.h:42-58 drawn on the device at every fresh root (on = 0: no noise); the
+ * reference seeds its gamma draws from random_device, so only the distribution is defined */
+int az_blokus_noise_device(az_blokus*, int on);
+/* The move loop of generate.cpp:37-123 for the G games.  Per move: a search of `budget` simulations from a fresh
+ * root (tower = NULL: the integer-hash evaluator), the row {planes, to move, search policy} buffered
+ * (generate.cpp:85), the move chosen -- sampled in proportion to the visits while the 1-based move number is below
+ * 0.2 x the running mean game length (initially 25), the first arg-max afterwards (generate.cpp:87-100) -- and
+ * played; a finished game hands its rows to a ring of `ring_rows` rows with the final reward (generate.cpp:110)
+ * and the next game starts in its slot.  Differences from the reference's loop, which cannot run this game: no
+ * tree reuse between moves and no warm-up search (every root is fresh), four-entry rewards, and a row's policy is
+ * kept sparse: entry j < counts[r] says policy[actions[j]] = probs[j] (= n_child / n_root, mcts.hpp:136-146) for
+ * the visited root children in action order, every other entry of the [91,20,20] policy being zero. */
+int az_blokus_selfplay_config(az_blokus*, int ring_rows);
+int az_blokus_selfplay_moves(az_blokus*, az_ctx* tower /* or NULL */, int budget, int n_moves);
+/* up to cap finished rows, oldest first, removed from the ring: planes u8 [cap,5,20,20], to_move u8 [cap],
+ * counts i32 [cap], actions i32 / probs f32 [cap,max_budget] (-1 / 0 beyond counts), reward f32 [cap,4] */
+int az_blokus_replay_drain(az_blokus*, int cap, uint8_t* planes, uint8_t* to_move, int32_t* counts,
+                           int32_t* actions, float* probs, float* reward, int32_t* n_rows);
+int az_blokus_selfplay_stats(az_blokus*, int64_t* moves, int64_t* games, int64_t* rows, int64_t* dropped);
 /* the orientation table: piece, bounding box, cells (row, column) row-major; returns the number of cells */
 int az_blokus_orient(int o, int* piece, int* h, int* w, int8_t* cells_yx /* [5][2] */);
 /* the same rules on the host, one game in caller memory of az_blokus_host_state_size() bytes (C++ Env shim,

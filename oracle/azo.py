@@ -329,3 +329,40 @@ def blokus_search(game, budget, noise=None, vl=3.0, c_puct=3.0):
     assert got == k
     out["root_n"], out["nodes"] = rn.value, nodes.value
     return out
+
+
+def blokus_selfplay(n_moves, budget, seed, slot, vl=3.0, c_puct=3.0):
+    """The move loop of generate.cpp:69-118 on one Blokus game of the oracle, as alphazero_amd/csrc/blokus.hip
+    states it for four players: per move a search of `budget` simulations from a fresh root, the row (planes,
+    to move, policy = n_child / n_root of the visited children in action order) buffered, the move sampled in
+    proportion to the visits while the 1-based move number is below 0.2 x the running mean game length
+    (initially 25; pick = (u * total) >> 32 with u = word 0 of Philox(seed ^ 'SAMP', slot, draws so far)), the first
+    arg-max afterwards; a finished game releases its rows with the final reward and the next game starts.
+    Returns (finished rows, moves played, games finished).  Test infrastructure: small cases only."""
+    g = Blokus()
+    avg_len, games, sample_ctr = np.float32(25.0), 0, 0
+    rows, pending, moves = [], [], 0
+    for _ in range(n_moves):
+        r = blokus_search(g, budget, None, vl, c_puct)
+        i = len(pending) + 1
+        vis = r["n"] > 0
+        pol = (r["n"][vis].astype(np.float32) / np.float32(r["root_n"])).astype(np.float32)
+        pending.append(dict(planes=g.planes(), to_move=g.to_move, actions=r["actions"][vis].copy(), probs=pol))
+        if float(i) < float(avg_len) * 0.2:
+            total = int(r["n"].sum())
+            pick = (philox(seed ^ 0x53414D50, slot, sample_ctr, 0) * total) >> 32
+            sample_ctr += 1
+            k = int(np.searchsorted(np.cumsum(r["n"].astype(np.int64)), pick, side="right"))
+        else:
+            k = int(np.argmax(r["n"]))
+        rew, done = g.step(int(r["actions"][k]))
+        moves += 1
+        if done == 1:
+            for row in pending:
+                row["reward"] = rew.copy()
+            rows += pending
+            pending = []
+            games += 1
+            avg_len = np.float32(avg_len + (np.float32(i) - avg_len) / np.float32(games))
+            g.reset()
+    return rows, moves, games

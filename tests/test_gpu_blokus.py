@@ -218,3 +218,87 @@ def test_search_with_the_tower_as_evaluator():
         vis = r["n"] > 0
         assert (np.abs(r["v"][vis] / r["n"][vis]) <= 1.0 + 1e-6).all() and (r["v"][~vis] == 0).all()
     assert dev.search_stats()["restarts"] == 0
+
+
+def _game_blocks(rows_planes, per_row):
+    """split rows (oldest first, each game's rows contiguous) into games at the empty-board rows"""
+    blocks, cur = [], []
+    for r, pl in enumerate(rows_planes):
+        if pl[:4].sum() == 0 and cur:
+            blocks.append(cur)
+            cur = []
+        cur.append(per_row(r))
+    if cur:
+        blocks.append(cur)
+    return blocks
+
+
+def test_selfplay_rows_match_the_oracle_bit_for_bit():
+    """The move loop (search from a fresh root, row, sampled or arg-max move, step, reward hand-over, next game)
+    on 3 games x 90 moves with the hash evaluator: every finished row -- planes, player to move, the visited
+    children's actions and n_child / n_root, the four-entry reward -- equals the oracle's loop, game by game."""
+    G, budget, n_moves, seed = 3, 6, 90, 11
+    dev = capi.Blokus(G, seed=seed)
+    dev.search_config(max_budget=budget)
+    dev.selfplay_config(ring_rows=G * 2 * 84, max_budget=budget)
+    dev.selfplay_moves(budget, n_moves)
+    st = dev.selfplay_stats()
+    got = dev.replay_drain(G * 2 * 84)
+    assert dev.selfplay_stats()["rows"] == 0 and st["dropped"] == 0 and st["moves"] == G * n_moves
+
+    def dev_row(r):
+        c = got["counts"][r]
+        return (got["planes"][r].tobytes(), int(got["to_move"][r]), got["actions"][r, :c].tobytes(), got["probs"][r, :c].tobytes(),
+                got["reward"][r].tobytes())
+    dev_games = sorted(_game_blocks(got["planes"], dev_row))
+    ref_games, ref_finished = [], 0
+    for g in range(G):
+        rows, moves, games = azo.blokus_selfplay(n_moves, budget, seed, g)
+        assert moves == n_moves
+        ref_finished += games
+        ref_games += _game_blocks([r["planes"] for r in rows],
+                                  lambda r, rows=rows: (rows[r]["planes"].tobytes(), int(rows[r]["to_move"]), rows[r]["actions"].astype(np.int32).tobytes(),
+                                                        rows[r]["probs"].tobytes(), rows[r]["reward"].tobytes()))
+    assert st["games"] == ref_finished >= G and len(got["counts"]) == sum(len(b) for b in ref_games)
+    assert dev_games == sorted(ref_games)
+    dense = capi.Blokus.dense_policy(got["actions"], got["probs"], got["counts"])
+    assert dense.shape[1:] == (91, 20, 20) and np.allclose(dense.reshape(len(dense), -1).sum(1), budget / (budget + 1.0), atol=1e-6)
+
+
+def test_selfplay_with_the_tower_and_device_noise():
+    """The same loop with the HIP tower as evaluator and Dirichlet noise drawn on the device: games finish, rows are
+    well-formed (policy mass n_root - 1 over n_root, legal first rows, rewards in {-1, 0, 1} with a winner)."""
+    from alphazero_amd import synth
+    G, budget = 8, 12
+    Cs = [128, 128, 128]
+    tower = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    tower.load_weights(synth.make_blob(20, 5, Cs, 5, c_out=91, value_dim=4))
+    dev = capi.Blokus(G, seed=5)
+    dev.search_config(max_budget=budget)
+    dev.noise_device(True)
+    dev.selfplay_config(ring_rows=G * 84, max_budget=budget)
+    dev.selfplay_moves(budget, 84, tower_engine=tower)          # a game has at most 84 moves
+    st = dev.selfplay_stats()
+    assert st["games"] >= G and st["moves"] == G * 84
+    got = dev.replay_drain(G * 84)
+    n = len(got["counts"])
+    assert n == st["rows"] + 0 and n >= G * 20
+    assert np.allclose(got["probs"].sum(1), budget / (budget + 1.0), atol=1e-6)
+    assert set(np.unique(got["reward"])) <= {-1.0, 0.0, 1.0} and (got["reward"].max(1) == 1.0).all()
+    first = got["planes"][:, :4].reshape(n, -1).sum(1) == 0
+    assert first.sum() == st["games"] and (got["to_move"][first] == 0).all()
+
+
+def test_search_survives_an_arena_too_small_for_the_position():
+    """edge_cap far below what 12 simulations of a mid-game position need: the search restarts once from a fresh
+    root, then ends with the simulations it has instead of restarting for ever; self-play carries on."""
+    G, budget = 4, 12
+    dev = capi.Blokus(G, seed=9)
+    dev.search_config(max_budget=budget, edge_cap=1500)
+    dev.selfplay_config(ring_rows=G * 84, max_budget=budget)
+    dev.selfplay_moves(budget, 40)
+    st, ss = dev.selfplay_stats(), dev.search_stats()
+    assert st["moves"] == G * 40 and ss["restarts"] > 0 and ss["max_slots"] <= 1500
+    for g in range(G):
+        r = dev.search_result(g)
+        assert 1 <= r["root_n"] <= budget + 1 and int(r["n"].sum()) == r["root_n"] - 1 and (r["n"] >= 0).all()

@@ -293,3 +293,24 @@ def test_blokus_shaped_tower_matches_torch_fp32(prec):
     assert np.allclose(pol.sum(1), 1.0, atol=1e-4) and np.allclose(val.sum(1), 2.0 - 4.0, atol=1e-5)
     with pytest.raises(capi.AzError, match="m,n,k search"):
         eng.search(1)                                   # this context is a tower, not an m,n,k searcher
+
+
+def test_odd_plane_and_channel_counts_match_torch_fp32():
+    """Plane and head counts neither game here uses (4 planes in, 2 policy channels, 3 values, 192 channels): the
+    generic stem kernel and row blocks of the head GEMM that are mostly padding, against the same torch fp32
+    statement of network.hpp:117-123."""
+    import torch
+    torch.set_num_threads(8)
+    N, B, Cs = 9, 5, [192, 192, 192]
+    blob = synth.make_blob(N, 4, Cs, 77, phead_gain=5.0, fc2_gain=3.0, c_out=2, value_dim=3)
+    planes = synth.random_planes(B, 4, N, seed=77)
+    eng = capi.Engine(N, 5, B, Cs=Cs, c_in=4, c_out=2, value_dim=3, max_budget=1)
+    assert not eng.tower_is_fused() and eng.weights_size() == blob.size
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(planes)
+    assert pol.shape == (B, 2 * 81) and val.shape == (B, 3)
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, blob, planes, c_out=2, value_dim=3)
+    print("4-plane 2-channel tower: policy err %.3g (max p %.3g) value err %.3g" % (np.abs(pol - rp).max(), rp.max(), np.abs(val - rv).max()))
+    assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
+    assert np.allclose(pol.sum(1), 1.0, atol=1e-4)

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--searches", type=int, default=3)
     ap.add_argument("--tower", action="store_true", help="evaluate the leaves with the HIP tower (NetConfig 2 on 20x20, 5 planes in, "
                                                          "91 policy channels, 4 values) instead of the integer-hash evaluator")
+    ap.add_argument("--selfplay-moves", type=int, default=0,
+                    help="afterwards play this many self-play moves of every game (search from a fresh root + move, Dirichlet "
+                         "noise drawn on the device, finished games restart in place) and report them under \"selfplay\"")
     a = ap.parse_args()
     from alphazero_amd import capi, synth
     dev = capi.Blokus(a.games, seed=3)
@@ -42,12 +45,29 @@ def main():
     st = dev.search_stats()
     _, count = dev.legal_mask(want_mask=False)
     sims = a.games * a.budget * a.searches
+    selfplay = None
+    if a.selfplay_moves > 0:
+        dev.reset()
+        dev.noise_device(True)
+        dev.selfplay_config(ring_rows=a.games * 84, max_budget=a.budget)
+        dev.selfplay_moves(a.budget, 1, tower_engine=tower)          # warm-up move
+        dev.sync()
+        t1 = time.perf_counter()
+        dev.selfplay_moves(a.budget, a.selfplay_moves, tower_engine=tower)
+        dev.sync()
+        el2 = time.perf_counter() - t1
+        sp = dev.selfplay_stats()
+        selfplay = {"moves_per_s": a.games * a.selfplay_moves / el2, "sims_per_s": a.games * a.selfplay_moves * a.budget / el2,
+                    "seconds": el2, "moves_timed": a.games * a.selfplay_moves, "games_finished": sp["games"], "rows_in_ring": sp["rows"],
+                    "rows_dropped": sp["dropped"], "tree": dev.search_stats(),
+                    "note": "from the empty board: one search of %d simulations from a fresh root per move, device Dirichlet noise" % a.budget}
     print(json.dumps({"metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
                       "config": {"workload": "blokus 20x20 4-player, %d concurrent games x %d sims per search, %s" % (
                                      a.games, a.budget, "NetConfig-2 tower (stem + 9 ResBlocks x 128 ch, 5 planes in, 91 policy channels, 4 values), "
                                      "fp16 operands, random-init weights" if a.tower else "integer-hash evaluator (env + tree kernels only)"),
                                  "pieces_on_board": a.pieces, "mean_legal_actions_at_root": float(count.mean())},
-                      "ms_per_round": el / (a.searches * (a.budget + 3)) * 1e3, "searches": a.searches, "seconds": el, "tree": st}))
+                      "ms_per_round": el / (a.searches * (a.budget + 3)) * 1e3, "searches": a.searches, "seconds": el, "tree": st,
+                      **({"selfplay": selfplay} if selfplay else {})}))
 
 
 if __name__ == "__main__":
