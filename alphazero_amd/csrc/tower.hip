@@ -844,11 +844,19 @@ __device__ __forceinline__ void fused_conv_taps(AccTile<J>& acc, int g, int tota
 // clock on this shape than on 32x32x16 at (almost) the same cycles per FLOP (tools/microbench/mfma_shape.hip),
 // and the fused tower is power-limited, so this is the default shape.  A wave's 128 channels x 32 J positions
 // are 8 channel blocks x 2 J position blocks of 16 x 16, one k-step covers K = 32:
-//   T[a][b][r] = channel 16 a + 4 g + r, position 16 b + l15 of the wave's rows   (l15 = lane & 15, g = lane >> 4)
-//   A fragment (weights), block a: row 16 a + l15 of the tap's [128][128] image, 16-byte piece 4 ks + g
-//   B fragment (activations), block b: LDS row of position 16 b + l15 (+ the tap's offset), piece 4 ks + g
-// so a lane still holds four consecutive channels of one position, and both fragment reads are conflict-free
-// ds_read_b128 on the images the 32x32x16 path uses (16 rows x 16 distinct XOR-ed pieces; 16 rows of 272 B).
+//   T[a][b][r] = channel 16 a + 4 gc + r, position 16 b + lp of the wave's rows
+//   A fragment (weights), block a: row 16 a + lp of the tap's [128][128] image, 16-byte piece ks + koff
+//   B fragment (activations), block b: LDS row of position 16 b + lp (+ the tap's offset), piece ks + koff
+// with, for lane = 16 g + l15:  lp = l15 ^ 4 below 8, l15 from 8 up;  gc = g ^ 1 below 2, g from 2 up;
+// koff = 0, 8, 4, 12 for g = 0..3.  The hardware fixes which lane feeds which MFMA row / column / k slice, not
+// which channel, position or 8-wide k slice that is, and the plain choice (lp = l15, piece 4 ks + g) costs a 2-way
+// bank conflict on every activation read: a ds_read_b128 is served in four groups of 16 lanes, {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} and the same + 32, i.e. half a k slice's lanes with the OTHER half of the next slice's.  On the
+// rotated activation image (17 slots of 16 B per row) the two halves land on disjoint slots only if their rows are
+// complementary sets closed under + 8 and their pieces differ by 8; on the XOR-ed weight image the same holds with
+// ^ 8.  lp sends lanes {0-3, 12-15} to rows {4-7, 12-15} and the rest to {0-3, 8-11}, and slices g, g + 1 of a
+// group read pieces p, p + 8: every group of both reads covers all 16 slots (SQ_LDS_BANK_CONFLICT: 27 % of the
+// LDS cycles before).  A lane still holds four consecutive channels of one position.
 // The MFMAs are inline asm with the accumulator tied in an AGPR quad: with the builtin the register allocator
 // copies accumulators around inside the loop.  What the compiler cannot see behind the asm is handled here:
 // wait states between the last MFMAs and the first read of their results, and between the epilogue's writes of
@@ -930,29 +938,29 @@ __device__ __forceinline__ void fused_epi_residual16(AccTile16<J>& X, const floa
 template <int PR, int J>
 __device__ __forceinline__ void fused_conv_taps16(AccTile16<J>& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
                                                   __amdgpu_buffer_rsrc_t wrsrc, unsigned st_off, unsigned char* st_dst,
-                                                  int posrow16, int W, int gq, int l15) {
+                                                  int posrow16, int W, int koff, int lp) {
     constexpr int NB = 2 * J;
 #define STAGE_W(g_, buf_, p_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
         wrsrc, (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, st_off, (g_) * (128 * 128 * 2) + (p_) * 4096, 0, 0)
     u32x4 fx[2][NB], fw[2][8];
-    const unsigned char* bA = sA + (posrow16 - W - 1) * A_STRIDE + gq * 16;        // tap 0: (-1,-1)
-    const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l15 * 256;
+    const unsigned char* bA = sA + (posrow16 - W - 1) * A_STRIDE + koff * 16;      // tap 0: (-1,-1)
+    const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + lp * 256;
 #pragma unroll
     for (int b = 0; b < NB; ++b) fx[0][b] = *(const u32x4*)(bA + b * 16 * A_STRIDE);
 #pragma unroll
-    for (int a = 0; a < 8; ++a) fw[0][a] = *(const u32x4*)(bB + a * 16 * 256 + ((gq ^ l15) << 4));
+    for (int a = 0; a < 8; ++a) fw[0][a] = *(const u32x4*)(bB + a * 16 * 256 + ((koff ^ lp) << 4));
     acc_fence16<J>(acc);
     asm volatile("s_nop 7");                                 // accumulator writes of the epilogue -> first MFMA
     for (int tap = 0; tap < 9; ++tap, ++g) {
         const int gn = g + 1 < total ? g + 1 : g;            // after the very last chunk: re-fetch it into the idle buffer
         const int tn = tap < 8 ? tap + 1 : 8;
-        const unsigned char* nA = sA + (posrow16 + (tn / 3 - 1) * W + (tn % 3 - 1)) * A_STRIDE + gq * 16;
-        const unsigned char* nB = sB + ((g + 1) & 1) * W_BUF_BYTES + l15 * 256;
+        const unsigned char* nA = sA + (posrow16 + (tn / 3 - 1) * W + (tn % 3 - 1)) * A_STRIDE + koff * 16;
+        const unsigned char* nB = sB + ((g + 1) & 1) * W_BUF_BYTES + lp * 256;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks & 1, n = c ^ 1;
-            const unsigned char* rA = ks < 3 ? bA + (ks + 1) * 64 : nA;
-            const unsigned char* rB = ks < 3 ? bB + ((((ks + 1) * 4 + gq) ^ l15) << 4) : nB + ((gq ^ l15) << 4);
+            const unsigned char* rA = ks < 3 ? bA + (ks + 1) * 16 : nA;
+            const unsigned char* rB = ks < 3 ? bB + (((ks + 1 + koff) ^ lp) << 4) : nB + ((koff ^ lp) << 4);
             if (ks == 3) {
                 // every wave holds its last fragments of this tap in registers and the next tap's weights
                 // have landed: hand the buffers over
@@ -1016,10 +1024,13 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int l15 = lane & 15, gq = lane >> 4;               // 16x16x32 shape: position / row inside a block, k quarter
+    const int l15 = lane & 15, gq = lane >> 4;               // 16x16x32 shape: MFMA row / column of the lane, k slice
+    const int lrc = l15 < 8 ? l15 ^ 4 : l15;                 // ... the position / channel row it stands for (see AccTile16)
+    const int gc = gq < 2 ? gq ^ 1 : gq;                     // ... the group of four channels its accumulators hold
+    const int koff = ((gq & 1) << 3) | ((gq & 2) << 1);      // ... the 16-byte piece its k slice starts from
     constexpr int NPB = SH == 16 ? 2 * J : J;                // position blocks of a wave
     constexpr int PBS = SH == 16 ? 16 : 32;                  // positions per block
-    const int lpos = SH == 16 ? l15 : l31;                   // this lane's position inside a block
+    const int lpos = SH == 16 ? lrc : l31;                    // this lane's position inside a block
     const int b0 = blockIdx.x * bpt;                         // first board of the tile
     const int nb_here = min(bpt, B - b0);
     const int rows_here = nb_here * P;                       // tile rows that belong to boards
@@ -1089,7 +1100,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     TSTAMP(41);
 
     typename TileOf<J, SH>::type X, Y;   // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
-    if constexpr (SH == 16) fused_bias_init16<J>(X, sBias, gq); else fused_bias_init(X, sBias, h);   // stem bias
+    if constexpr (SH == 16) fused_bias_init16<J>(X, sBias, gc); else fused_bias_init(X, sBias, h);   // stem bias
 
     // which of this lane's positions are real board cells
     float keepcap[NPB];
@@ -1104,9 +1115,9 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         // stem: the im2col tile is exactly one k-step of 32
         u32x4 xb[NPB], wa[8];
 #pragma unroll
-        for (int b = 0; b < NPB; ++b) xb[b] = *(const u32x4*)(sI + (PW * wv + 16 * b + l15) * I_STRIDE + gq * 16);
+        for (int b = 0; b < NPB; ++b) xb[b] = *(const u32x4*)(sI + (PW * wv + 16 * b + lrc) * I_STRIDE + gq * 16);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) wa[a] = *(const u32x4*)(sW + (16 * a + l15) * I_STRIDE + gq * 16);
+        for (int a = 0; a < 8; ++a) wa[a] = *(const u32x4*)(sW + (16 * a + lrc) * I_STRIDE + gq * 16);
         acc_fence16<J>(X);
         asm volatile("s_nop 7");
 #pragma unroll
@@ -1133,10 +1144,10 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();                                         // every wave is done with sI / sW
     TSTAMP(42);
     // bias table: [0] stem, [1 + L] convolution L.  Block b = convolutions 2b (onto Y) and 2b+1 (onto X).
-    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + lpos) * A_STRIDE + 8 * (SH == 16 ? gq : h);
+    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + lpos) * A_STRIDE + 8 * (SH == 16 ? gc : h);
     if constexpr (SH == 16) {
-        fused_epi_residual16<PR, J>(X, sBias + 2 * 128, row0, keepcap, gq);
-        fused_bias_init16<J>(Y, sBias + 1 * 128, gq);
+        fused_epi_residual16<PR, J>(X, sBias + 2 * 128, row0, keepcap, gc);
+        fused_bias_init16<J>(Y, sBias + 1 * 128, gc);
     } else {
         fused_epi_residual<PR, J>(X, sBias + 2 * 128, row0, keepcap, h);
         fused_bias_init(Y, sBias + 1 * 128, h);
@@ -1165,18 +1176,18 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     for (int b = 0; b < n_blocks; ++b) {
         // next block's biases; after the last block X restarts from the zero row: the heads read relu(x) itself
         const int nb1 = min(3 + 2 * b, n_layers), nb2 = b + 1 < n_blocks ? 4 + 2 * b : n_layers + 1;
-        if constexpr (SH == 16) fused_conv_taps16<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, gq, l15);
+        if constexpr (SH == 16) fused_conv_taps16<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, koff, lrc);
         else fused_conv_taps<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         // (the barrier before the last k-step: all waves have finished reading this layer's input)
         TSTAMP(2 + 4 * b);
-        if constexpr (SH == 16) fused_epi_hidden16<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, gq);
+        if constexpr (SH == 16) fused_epi_hidden16<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, gc);
         else fused_epi_hidden<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, h);
         __syncthreads();
         TSTAMP(3 + 4 * b);
-        if constexpr (SH == 16) fused_conv_taps16<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, gq, l15);
+        if constexpr (SH == 16) fused_conv_taps16<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, koff, lrc);
         else fused_conv_taps<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
         TSTAMP(4 + 4 * b);
-        if constexpr (SH == 16) fused_epi_residual16<PR, J>(X, sBias + nb2 * 128, row0, keepcap, gq);
+        if constexpr (SH == 16) fused_epi_residual16<PR, J>(X, sBias + nb2 * 128, row0, keepcap, gc);
         else fused_epi_residual<PR, J>(X, sBias + nb2 * 128, row0, keepcap, h);
         __syncthreads();
         TSTAMP(5 + 4 * b);
@@ -1208,11 +1219,11 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 #pragma unroll
         for (int j = 0; j < NPB; ++j) spv[j] = (f32x2){0.f, 0.f};
         if constexpr (SH == 16) {
-            // a lane holds 32 of the 128 channels of each of its positions (16 a + 4 gq + r); lanes ^ 16, ^ 32 the rest
+            // a lane holds 32 of the 128 channels of each of its positions (16 a + 4 gc + r); lanes ^ 16, ^ 32 the rest
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                const float4 w01 = *(const float4*)(hp + 2 * (16 * a + 4 * gq));
-                const float4 w23 = *(const float4*)(hp + 2 * (16 * a + 4 * gq) + 4);
+                const float4 w01 = *(const float4*)(hp + 2 * (16 * a + 4 * gc));
+                const float4 w23 = *(const float4*)(hp + 2 * (16 * a + 4 * gc) + 4);
 #pragma unroll
                 for (int j = 0; j < NPB; ++j) {
                     const float x0 = X[a][j][0], x1 = X[a][j][1], x2 = X[a][j][2], x3 = X[a][j][3];
@@ -1230,7 +1241,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                 lp += __shfl_xor(lp, 32, 64);
                 lv += __shfl_xor(lv, 32, 64);
                 if (gq == 0) {
-                    const int row = PW * wv + 16 * j + l15;
+                    const int row = PW * wv + 16 * j + lrc;
                     const bool real = keepcap[j] != 0.f;
                     s_logit[row] = real ? lp + bp : -3.4e38f;
                     s_u[row] = real ? fmaxf(lv + bvv, 0.f) : 0.f;
