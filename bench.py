@@ -87,13 +87,13 @@ def main():
     ap.add_argument("--config", type=int, choices=[1, 2, 3, 4], default=None,
                     help="preset of BASELINE.json configs[i]: 1 = 9x9, 256 games, 400 sims/move; 2 = the default "
                          "(15x15, 512 games per GPU, 800 sims/move); 3 = blokus 20x20 4-player, 2048 games x 400 sims with "
-                         "the tower as evaluator (runs tools/blokus_search_bench.py --tower, single GPU); 4 = tower only, "
+                         "the tower as evaluator, three searches then three self-play moves (runs tools/blokus_search_bench.py, single GPU); 4 = tower only, "
                          "20 blocks x 256 channels, batch 8192 (runs tools/tower_bench.py, single GPU)")
     args = ap.parse_args()
     if args.config == 1:
         args.board, args.games, args.budget = 9, 256, 400
     elif args.config == 3:
-        sys.argv = [os.path.join(ROOT, "tools", "blokus_search_bench.py"), "--tower"]
+        sys.argv = [os.path.join(ROOT, "tools", "blokus_search_bench.py"), "--tower", "--selfplay-moves", "3"]
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import blokus_search_bench
         return blokus_search_bench.main()

@@ -302,3 +302,25 @@ def test_search_survives_an_arena_too_small_for_the_position():
     for g in range(G):
         r = dev.search_result(g)
         assert 1 <= r["root_n"] <= budget + 1 and int(r["n"].sum()) == r["root_n"] - 1 and (r["n"] >= 0).all()
+
+
+def test_selfplay_at_config_size_keeps_its_books():
+    """2 048 games in lockstep (BASELINE's Blokus size) with a short budget: every game advances one move per
+    call, nobody is stuck, finished games hand over exactly their rows, and the books add up."""
+    G, budget, n_moves = 2048, 8, 30
+    dev = capi.Blokus(G, seed=21)
+    dev.search_config(max_budget=budget)
+    dev.noise_device(True)
+    dev.selfplay_config(ring_rows=G * 30, max_budget=budget)
+    dev.selfplay_moves(budget, n_moves)
+    st, ss, state = dev.selfplay_stats(), dev.search_stats(), dev.state()
+    assert st["moves"] == G * n_moves and st["dropped"] == 0 and ss["restarts"] == 0
+    assert not state["over"].any()
+    # rows in the ring + moves of the games still in progress = all moves played
+    assert st["rows"] + int(state["moves"].sum()) == G * n_moves
+    got = dev.replay_drain(G * 30)
+    assert len(got["counts"]) == st["rows"]
+    if st["rows"]:
+        assert (got["counts"] >= 1).all() and (got["counts"] <= budget).all()
+        assert np.allclose(got["probs"].sum(1), budget / (budget + 1.0), atol=1e-6)
+        assert (got["reward"].max(1) == 1.0).all()
