@@ -411,7 +411,7 @@ template <int PR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
                        float* resid /* fp32 residual stream, updated in place; null: none */, const unsigned short* __restrict__ wpk,
-                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu) {
+                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu, int xcd_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Prec<PR>::vec vec;
     const int W = N + 1, P = W * W;
@@ -424,8 +424,19 @@ az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* __
     const int lane = tid & 63, wv = tid >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const int l31 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * T4_M;
-    const int nb = blockIdx.y;
+    // Workgroups go to the eight XCDs round robin by their linear index, each XCD with an L2 of its own.  Index
+    // -> (tile, output-channel block) so that an XCD works through one contiguous eighth of the tiles with the
+    // channel blocks of a tile back to back: the second block finds the tile's input rows in that L2, and so does
+    // the next tile for the halo rows it shares.  AZ_T256_PLAIN_ORDER (host) keeps the plain (x = tile, y = block) order.
+    int tile_i = blockIdx.x, nb = blockIdx.y;
+    if (gridDim.y == 1 && xcd_tiles > 0) {
+        const int n_nb = C_pad / 128;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nb = slot % n_nb;
+        tile_i = xcd * xcd_tiles + slot / n_nb;
+        if (slot / n_nb >= xcd_tiles || tile_i >= n_tiles) return;
+    }
+    const int m0 = tile_i * T4_M;
     const int n_sc = C_pad / 128;
     const int n_kc = C_pad / 64;
     const int total = n_kc * 9;                              // (slice, tap) chunks
@@ -1557,8 +1568,14 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short*
         const int tiles = (M + T4_M - 1) / T4_M;
         size_t sm = 2 * (size_t)W2_BYTES + (size_t)t4_slab_rows(Gd) * 128;
         if (sm < (size_t)T4_M * 256) sm = (size_t)T4_M * 256;               // the epilogue image
-        BY_PREC(az_conv3x3_t256_kernel, dim3(tiles, C_pad / 128), dim3(256), sm, s,
-                in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu);
+        if (getenv("AZ_T256_PLAIN_ORDER")) {
+            BY_PREC(az_conv3x3_t256_kernel, dim3(tiles, C_pad / 128), dim3(256), sm, s,
+                    in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, 0);
+            return;
+        }
+        const int xcd_tiles = (tiles + 7) / 8;
+        BY_PREC(az_conv3x3_t256_kernel, dim3(8 * xcd_tiles * (C_pad / 128)), dim3(256), sm, s,
+                in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, xcd_tiles);
         return;
     }
     const int tiles = (M + T2_M - 1) / T2_M;
