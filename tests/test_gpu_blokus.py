@@ -324,3 +324,28 @@ def test_selfplay_at_config_size_keeps_its_books():
         assert (got["counts"] >= 1).all() and (got["counts"] <= budget).all()
         assert np.allclose(got["probs"].sum(1), budget / (budget + 1.0), atol=1e-6)
         assert (got["reward"].max(1) == 1.0).all()
+
+
+def test_replay_drain_in_pieces_equals_one_drain():
+    """Two identical runs (hash evaluator, same seed): draining 7 rows at a time returns the same rows in the same
+    order as one big drain, and leaves the ring empty."""
+    G, budget, n_moves = 3, 4, 75
+    runs = []
+    for _ in range(2):
+        dev = capi.Blokus(G, seed=33)
+        dev.search_config(max_budget=budget)
+        dev.selfplay_config(ring_rows=G * 84, max_budget=budget)
+        dev.selfplay_moves(budget, n_moves)
+        runs.append(dev)
+    whole = runs[0].replay_drain(G * 84)
+    n = len(whole["counts"])
+    assert n >= 50
+    parts = []
+    while True:
+        got = runs[1].replay_drain(7)
+        if len(got["counts"]) == 0:
+            break
+        parts.append(got)
+    assert runs[1].selfplay_stats()["rows"] == 0
+    for key in ("planes", "to_move", "counts", "actions", "probs", "reward"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key]), key
