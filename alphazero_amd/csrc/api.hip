@@ -72,6 +72,7 @@ struct az_ctx {
     // misc device scratch
     int* d_actions = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; int* d_illegal = nullptr;
     uint8_t* d_export = nullptr;                          // [G][3][A] planes or [G][A] mask of az_env_boards / az_env_legal_mask
+    unsigned long long* d_stats = nullptr;                // [32] az_get_stats' reduction
     int mode = AZ_MODE_SEARCH;
     bool search_active = false;
     int64_t rounds = 0;
@@ -211,6 +212,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     AZCHK(dalloc(c, &c->d_actions, G)); AZCHK(dalloc(c, &c->d_reward, 2 * (size_t)G));
     AZCHK(dalloc(c, &c->d_done, G)); AZCHK(dalloc(c, &c->d_illegal, 4));
     AZCHK(dalloc(c, &c->d_export, (size_t)G * 3 * A));
+    AZCHK(dalloc(c, &c->d_stats, 32));
     if (az_tree_configure(&d) != 0) return fail(AZ_E_HIP, "tree kernel LDS configuration failed (node_cap %d)", d.node_cap);
 
     c->Bmax = (int)S;
@@ -834,37 +836,24 @@ extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_m
 extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     NEED(c); NEED(s);
     HIPCHK(hipSetDevice(c->cfg.device));
+    // one reduction kernel behind the queued work and one 256-byte copy
+    unsigned long long k[32];
+    az_launch_stats(c->stream, &c->d, c->d_stats);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(k, c->d_stats, sizeof k, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int G = c->cfg.G;
-    unsigned long long k[16];
-    HIPCHK(hipMemcpy(k, c->d.counters, sizeof k, hipMemcpyDeviceToHost));
-    std::vector<int> err(G), st(G), sd(G), nn(G), ne(G), hn(G), he(G);
-    std::vector<unsigned long long> gc((size_t)G * AZ_GC_STRIDE);
-    HIPCHK(hipMemcpy(err.data(), c->d.err, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(st.data(), c->d.status, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(sd.data(), c->d.sims_done, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(nn.data(), c->d.n_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ne.data(), c->d.n_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hn.data(), c->d.g_hw_nodes, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(he.data(), c->d.g_hw_edges, sizeof(int) * G, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(gc.data(), c->d.g_ctr, sizeof(unsigned long long) * gc.size(), hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
     s->sims = (int64_t)k[0]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
     s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
     s->rounds = c->rounds;
+    s->evals = (int64_t)k[16]; s->descents = (int64_t)k[17]; s->tree_levels = (int64_t)k[18];
+    s->children_scanned = (int64_t)k[19]; s->children_expanded = (int64_t)k[20];
+    s->tree_restarts = (int32_t)k[21];
     // simulations backed up = those of completed searches + the progress of searches in flight
-    s->sims_backed_up = (int64_t)k[0];
-    for (int g = 0; g < G; ++g) {
-        const unsigned long long* q = gc.data() + (size_t)g * AZ_GC_STRIDE;
-        s->evals += (int64_t)q[AZ_GC_EVALS]; s->descents += (int64_t)q[AZ_GC_DESCENTS];
-        s->tree_levels += (int64_t)q[AZ_GC_LEVELS]; s->children_scanned += (int64_t)q[AZ_GC_SCANNED];
-        s->children_expanded += (int64_t)q[AZ_GC_EXPANDED];
-        s->tree_restarts += (int32_t)q[AZ_GC_RESTARTS];
-        if (st[g] == AZ_ST_RUN) s->sims_backed_up += sd[g];
-        s->max_nodes = std::max(s->max_nodes, std::max(hn[g], nn[g]));
-        s->max_edges = std::max(s->max_edges, std::max(he[g], ne[g]));
-        s->error_games += err[g] != 0;
-    }
+    s->sims_backed_up = (int64_t)(k[0] + k[22]);
+    s->error_games = (int32_t)k[23];
+    s->max_nodes = (int32_t)k[24];
+    s->max_edges = (int32_t)k[25];
     return AZ_OK;
 }
 

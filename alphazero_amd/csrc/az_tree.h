@@ -8,6 +8,7 @@ int  az_tree_configure(const AzTreeDev* d);
 void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode, int g0, int count);
 void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget);
 void az_launch_selfplay_begin(hipStream_t s, const AzTreeDev* d);
+void az_launch_stats(hipStream_t s, const AzTreeDev* d, unsigned long long* out);   // out: 32 words, see az_stats_kernel
 void az_launch_env_step(hipStream_t s, const AzTreeDev* d, const int* actions, float* reward,
                         uint8_t* done, int* illegal);
 void az_launch_env_reset(hipStream_t s, const AzTreeDev* d);

@@ -785,6 +785,42 @@ extern "C" void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mas
 extern "C" void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget) {
     hipLaunchKernelGGL(az_begin_kernel, dim3(d->G), dim3(AZ_WAVE), tree_smem(*d), s, *d, budget);
 }
+// The tallies az_get_stats reports, reduced over the games on the device: out[0..15] = the context's counters,
+// out[16..] = evals, descents, tree levels, children scanned, children expanded, restarts, simulations of searches
+// in flight, games in error (sums), then the largest node and edge counts (maxima).
+extern "C" __global__ void __launch_bounds__(256) az_stats_kernel(AzTreeDev d, unsigned long long* out) {
+    __shared__ unsigned long long s_sum[8][4];
+    __shared__ int s_max[2][4];
+    unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int mx[2] = {0, 0};
+    for (int g = threadIdx.x; g < d.G; g += 256) {
+        const unsigned long long* q = d.g_ctr + (size_t)g * AZ_GC_STRIDE;
+        sum[0] += q[AZ_GC_EVALS]; sum[1] += q[AZ_GC_DESCENTS]; sum[2] += q[AZ_GC_LEVELS];
+        sum[3] += q[AZ_GC_SCANNED]; sum[4] += q[AZ_GC_EXPANDED]; sum[5] += q[AZ_GC_RESTARTS];
+        if (d.status[g] == AZ_ST_RUN) sum[6] += (unsigned long long)d.sims_done[g];
+        sum[7] += d.err[g] != 0;
+        mx[0] = max(mx[0], max(d.g_hw_nodes[g], d.n_nodes[g]));
+        mx[1] = max(mx[1], max(d.g_hw_edges[g], d.n_edges[g]));
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < 8; ++k) {
+        for (int o = 32; o > 0; o >>= 1) sum[k] += __shfl_xor(sum[k], o, 64);
+        if (lane == 0) s_sum[k][wv] = sum[k];
+    }
+    for (int k = 0; k < 2; ++k) {
+        for (int o = 32; o > 0; o >>= 1) mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64));
+        if (lane == 0) s_max[k][wv] = mx[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) out[threadIdx.x] = d.counters[threadIdx.x];
+    if (threadIdx.x < 8) out[16 + threadIdx.x] = s_sum[threadIdx.x][0] + s_sum[threadIdx.x][1] + s_sum[threadIdx.x][2] + s_sum[threadIdx.x][3];
+    if (threadIdx.x < 2)
+        out[24 + threadIdx.x] = (unsigned long long)max(max(s_max[threadIdx.x][0], s_max[threadIdx.x][1]), max(s_max[threadIdx.x][2], s_max[threadIdx.x][3]));
+}
+extern "C" void az_launch_stats(hipStream_t s, const AzTreeDev* d, unsigned long long* out) {
+    hipLaunchKernelGGL(az_stats_kernel, dim3(1), dim3(256), 0, s, *d, out);
+}
+
 extern "C" void az_launch_selfplay_begin(hipStream_t s, const AzTreeDev* d) {
     hipLaunchKernelGGL(az_selfplay_begin_kernel, dim3((d->G + 63) / 64), dim3(64), 0, s, *d);
 }
