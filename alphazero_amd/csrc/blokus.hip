@@ -702,6 +702,8 @@ extern "C" __global__ void __launch_bounds__(64) azb_selfplay_move_kernel(AzbDev
     azb_play(d, g, s_pick, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta, nullptr, nullptr);   // generate.cpp:103
     if (!s_meta[1]) return;
     // game over: buffer.send_reward(reward), stats, env.reset() (generate.cpp:110-118,75)
+    __threadfence_block();                           // this move's row and the final reward were written by other lanes of the wave
+    __syncthreads();
     int base = -1;
     if (lane == 0) {
         unsigned long long old = atomicAdd(&d.sp_counters[0], 0ull);
