@@ -421,6 +421,7 @@ class Blokus:
     # -- MCTS ----------------------------------------------------------------
     def search_config(self, vl=3.0, c_puct=3.0, max_budget=400, edge_cap=0):
         _chk(load().az_blokus_search_config(self.h, vl, c_puct, int(max_budget), int(edge_cap)))
+        self.K = int(max_budget)                    # policy entries kept per self-play row
 
     def set_noise(self, noise):
         if noise is None:
@@ -464,9 +465,9 @@ class Blokus:
         _chk(load().az_blokus_noise_device(self.h, int(bool(on))))
 
     # -- self-play -------------------------------------------------------------
-    def selfplay_config(self, ring_rows, max_budget):
-        """max_budget: the value given to search_config (entries kept per row)"""
-        self.K = int(max_budget)
+    def selfplay_config(self, ring_rows, max_budget=None):
+        """after search_config; max_budget, if given, must be the value search_config got"""
+        assert max_budget is None or int(max_budget) == getattr(self, "K", None)
         _chk(load().az_blokus_selfplay_config(self.h, int(ring_rows)))
 
     def selfplay_moves(self, budget, n_moves, tower_engine=None):
