@@ -295,22 +295,24 @@ def test_blokus_shaped_tower_matches_torch_fp32(prec):
         eng.search(1)                                   # this context is a tower, not an m,n,k searcher
 
 
-def test_odd_plane_and_channel_counts_match_torch_fp32():
-    """Plane and head counts neither game here uses (4 planes in, 2 policy channels, 3 values, 192 channels): the
-    generic stem kernel and row blocks of the head GEMM that are mostly padding, against the same torch fp32
-    statement of network.hpp:117-123."""
+@pytest.mark.parametrize("c_in,c_out,vd,C", [(4, 2, 3, 192), (5, 100, 2, 128)], ids=["4in-2out-3val-192ch", "5in-100out-128ch"])
+def test_odd_plane_and_channel_counts_match_torch_fp32(c_in, c_out, vd, C):
+    """Plane and head counts neither game here uses: the generic stem kernel (4 planes), row blocks of the head
+    GEMM that are mostly padding (2 policy channels, 192 channels in a 256-wide image) and a head with more than
+    three row blocks (100 policy channels + the value channel = four blocks of 32, taken in two groups), against
+    the same torch fp32 statement of network.hpp:117-123."""
     import torch
     torch.set_num_threads(8)
-    N, B, Cs = 9, 5, [192, 192, 192]
-    blob = synth.make_blob(N, 4, Cs, 77, phead_gain=5.0, fc2_gain=3.0, c_out=2, value_dim=3)
-    planes = synth.random_planes(B, 4, N, seed=77)
-    eng = capi.Engine(N, 5, B, Cs=Cs, c_in=4, c_out=2, value_dim=3, max_budget=1)
+    N, B, Cs = 9, 5, [C, C, C]
+    blob = synth.make_blob(N, c_in, Cs, 77, phead_gain=5.0, fc2_gain=3.0, c_out=c_out, value_dim=vd)
+    planes = synth.random_planes(B, c_in, N, seed=77)
+    eng = capi.Engine(N, 5, B, Cs=Cs, c_in=c_in, c_out=c_out, value_dim=vd, max_budget=1)
     assert not eng.tower_is_fused() and eng.weights_size() == blob.size
     eng.load_weights(blob)
     pol, val = eng.tower_forward(planes)
-    assert pol.shape == (B, 2 * 81) and val.shape == (B, 3)
+    assert pol.shape == (B, c_out * 81) and val.shape == (B, vd)
     with torch.no_grad():
-        rp, rv = torch_reference(N, Cs, blob, planes, c_out=2, value_dim=3)
-    print("4-plane 2-channel tower: policy err %.3g (max p %.3g) value err %.3g" % (np.abs(pol - rp).max(), rp.max(), np.abs(val - rv).max()))
+        rp, rv = torch_reference(N, Cs, blob, planes, c_out=c_out, value_dim=vd)
+    print("odd-shaped tower: policy err %.3g (max p %.3g) value err %.3g" % (np.abs(pol - rp).max(), rp.max(), np.abs(val - rv).max()))
     assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
     assert np.allclose(pol.sum(1), 1.0, atol=1e-4)
