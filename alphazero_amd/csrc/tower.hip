@@ -686,188 +686,34 @@ extern "C" int az_tower_timing_read(unsigned long long* out) {
 #define TSTAMP(slot_) do {} while (0)
 #endif
 
-// Accumulator tile of one wave in the MFMA C/D layout: 128 channels x 32 J positions (J = 2: 256-row
-// workgroup tiles; J = 1: 128-row tiles for small boards, so that a small batch still fills the chip).
-// T[i][j][4q+c] = channel 32i + 8q + 4h + c, position 32j + l31 of the wave's 32 J rows.
-template <int J> using AccTile = f32x16[4][J];
-
-// T = bias[channel], broadcast over positions (the convolution then accumulates on top).
-template <int J>
-__device__ __forceinline__ void fused_bias_init(AccTile<J>& T, const float* bptr, int h) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = *(const float4*)(bptr + 32 * i + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                T[i][j][4 * q + 0] = bv.x; T[i][j][4 * q + 1] = bv.y;
-                T[i][j][4 * q + 2] = bv.z; T[i][j][4 * q + 3] = bv.w;
-            }
-        }
-}
-
-// First convolution of a ResBlock (network.hpp:33): h = relu(Y) goes to LDS as 16-bit
-// activations, and Y restarts from the bias of the next block's first convolution.
-template <int PR, int J>
-__device__ __forceinline__ void fused_epi_hidden(AccTile<J>& Y, const float* next_bias, unsigned char* row0,
-                                                 const float (&caps)[J], int h) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = *(const float4*)(next_bias + 32 * i + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const float cap = caps[j];
-                uint2 o;
-                o.x = Prec<PR>::pack2(relu_cap(Y[i][j][4 * q + 0], cap), relu_cap(Y[i][j][4 * q + 1], cap));
-                o.y = Prec<PR>::pack2(relu_cap(Y[i][j][4 * q + 2], cap), relu_cap(Y[i][j][4 * q + 3], cap));
-                *(uint2*)(row0 + j * 32 * A_STRIDE + (32 * i + 8 * q) * 2) = o;
-                Y[i][j][4 * q + 0] = bv.x; Y[i][j][4 * q + 1] = bv.y;
-                Y[i][j][4 * q + 2] = bv.z; Y[i][j][4 * q + 3] = bv.w;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);       // 32 values at a time: short live ranges, no spills
-    }
-}
-
-// Stem and second convolution of a ResBlock (network.hpp:34-37): X already holds
-// residual + bias + convolution (it was accumulated in place), so x = relu(X) is both
-// the new fp32 residual and, rounded to 16 bits, the next layer's input in LDS; X then
-// takes the bias of the next block's second convolution on top of the residual.  The
-// residual of a padding row is held at zero too (it only ever feeds itself).
-template <int PR, int J>
-__device__ __forceinline__ void fused_epi_residual(AccTile<J>& X, const float* next_bias, unsigned char* row0,
-                                                   const float (&caps)[J], int h) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = *(const float4*)(next_bias + 32 * i + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const float cap = caps[j];
-                const float r0 = relu_cap(X[i][j][4 * q + 0], cap), r1 = relu_cap(X[i][j][4 * q + 1], cap);
-                const float r2 = relu_cap(X[i][j][4 * q + 2], cap), r3 = relu_cap(X[i][j][4 * q + 3], cap);
-                uint2 o;
-                o.x = Prec<PR>::pack2(r0, r1);
-                o.y = Prec<PR>::pack2(r2, r3);
-                *(uint2*)(row0 + j * 32 * A_STRIDE + (32 * i + 8 * q) * 2) = o;
-                X[i][j][4 * q + 0] = r0 + bv.x; X[i][j][4 * q + 1] = r1 + bv.y;
-                X[i][j][4 * q + 2] = r2 + bv.z; X[i][j][4 * q + 3] = r3 + bv.w;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// One 3x3 convolution (nine taps) accumulated onto `acc`.  Weight chunk g + tap sits in
-// buffer (g + tap) & 1 when the tap starts; chunk g + tap + 1 streams in behind it.
-// One chunk = one tap = [n=128][k=128] 16-bit = 32 KB, copied global -> LDS by the DMA path
-// (global_load_lds, 16 B per lane, no staging registers).  The LDS image is lane-linear,
-// so the bank-conflict fix is an XOR swizzle applied to the SOURCE address and again on
-// the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
-template <int PR, int J>
-__device__ __forceinline__ void fused_conv_taps(AccTile<J>& acc, int g, int total, const unsigned char* sA, unsigned char* sB,
-                                                __amdgpu_buffer_rsrc_t wrsrc, unsigned st_off, unsigned char* st_dst,
-                                                int posrow0, int W, int h, int l31) {
-    const int swz = l31 & 15;
-    // buffer-addressed form of the LDS DMA: scalar resource + scalar chunk offset + per-lane
-    // 32-bit offset (no 64-bit vector address arithmetic), and the compiler keeps counted
-    // s_waitcnt lgkmcnt(N) for the fragment reads while pieces are in flight (with the
-    // global_load_lds form it drains the LDS queue to zero before every dependent MFMA)
-#define STAGE_W(g_, buf_, p_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
-        wrsrc, (lds_void*)(st_dst + (buf_) * W_BUF_BYTES + (p_) * 4096), 16, st_off, (g_) * (128 * 128 * 2) + (p_) * 4096, 0, 0)
-    // fragments double-buffered in registers: the reads of the next k-step are issued
-    // ahead of the MFMAs of the current one (one wave per SIMD, so nothing else hides
-    // the LDS latency), and the pipeline runs across tap boundaries: the barrier that
-    // hands over the weight buffers sits before the LAST k-step of a tap, whose MFMAs
-    // then cover the first fragment reads of the next tap.
-    typename Prec<PR>::vec fx[2][J], fw[2][4];
-    const unsigned char* bA = sA + (posrow0 - W - 1) * A_STRIDE + h * 16;          // tap 0: (-1,-1)
-    const unsigned char* bB = sB + (g & 1) * W_BUF_BYTES + l31 * 256;
-#pragma unroll
-    for (int j = 0; j < J; ++j) fx[0][j] = *(const typename Prec<PR>::vec*)(bA + j * 32 * A_STRIDE);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fw[0][i] = *(const typename Prec<PR>::vec*)(bB + i * 32 * 256 + ((h ^ swz) << 4));
-    for (int tap = 0; tap < 9; ++tap, ++g) {
-#ifdef AZ_TOWER_TIMING
-        if (g >= 72 && g < 81 && blockIdx.x == 0 && threadIdx.x == 0) az_tower_ts[0][45 + tap] = __builtin_readcyclecounter();
-#endif
-        // the chunk after this one; after the very last chunk the DMA re-fetches it into the idle
-        // buffer (nobody reads that): no branch in the k-step code
-        const int gn = g + 1 < total ? g + 1 : g;
-        // the tap after this one (the last tap of a layer re-reads itself: harmless, unused)
-        const int tn = tap < 8 ? tap + 1 : 8;
-        const unsigned char* nA = sA + (posrow0 + (tn / 3 - 1) * W + (tn % 3 - 1)) * A_STRIDE + h * 16;
-        const unsigned char* nB = sB + ((g + 1) & 1) * W_BUF_BYTES + l31 * 256;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            // One k-step = 8 MFMAs in a fixed order with the six fragment reads of the NEXT k-step
-            // behind its first three MFMAs, two per gap, in the reverse of the order the next k-step
-            // consumes them (its first MFMA then waits for the whole batch once; every read has five
-            // MFMAs, ~160 cycles, to return; measured 0.5 % faster than one read per gap) and, in
-            // the first four k-steps, two 4 KB pieces of the next tap's weights (the last piece
-            // still has three k-steps, ~750 cycles, to land before the hand-over barrier).
-            const int c = ks & 1, n = c ^ 1;
-            const unsigned char* rA = ks < 7 ? bA + (ks + 1) * 32 : nA;
-            const unsigned char* rB = ks < 7 ? bB + ((((ks + 1) * 2 + h) ^ swz) << 4) : nB + ((h ^ swz) << 4);
-            if (ks == 7) {
-                // every wave holds its last fragments of this tap in registers and the next
-                // tap's weights have landed: hand the buffers over
-                AZ_DMA_LANDED();
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#define MF_(i_, j_) acc[i_][j_] = Prec<PR>::mfma(fw[c][i_], fx[c][j_], acc[i_][j_])
-#define FENCE_ __builtin_amdgcn_sched_barrier(0)
-            if constexpr (J == 2) {
-                MF_(0, 0); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 256); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 256); FENCE_;
-                MF_(0, 1); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 256); fx[n][1] = *(const typename Prec<PR>::vec*)(rA + 32 * A_STRIDE); FENCE_;
-                MF_(1, 0); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); fx[n][0] = *(const typename Prec<PR>::vec*)(rA); FENCE_;
-                MF_(1, 1); FENCE_;
-                MF_(2, 0); FENCE_;
-                MF_(2, 1); FENCE_;
-                MF_(3, 0);
-                if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
-                FENCE_;
-                MF_(3, 1); FENCE_;
-            } else {
-                // 128-row tiles: 4 MFMAs per k-step on one activation and four weight fragments
-                MF_(0, 0); fx[n][0] = *(const typename Prec<PR>::vec*)(rA); fw[n][0] = *(const typename Prec<PR>::vec*)(rB); FENCE_;
-                MF_(1, 0); fw[n][1] = *(const typename Prec<PR>::vec*)(rB + 32 * 256); FENCE_;
-                MF_(2, 0); fw[n][2] = *(const typename Prec<PR>::vec*)(rB + 2 * 32 * 256); fw[n][3] = *(const typename Prec<PR>::vec*)(rB + 3 * 32 * 256); FENCE_;
-                MF_(3, 0);
-                if (ks < 4) { STAGE_W(gn, (g + 1) & 1, 2 * ks); STAGE_W(gn, (g + 1) & 1, 2 * ks + 1); }
-                FENCE_;
-            }
-#undef MF_
-#undef FENCE_
-        }
-        bA = nA; bB = nB;
-    }
-#undef STAGE_W
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// The same wave tile on v_mfma_f32_16x16x32_{bf16,f16}: on random operands the chip holds a 12-14 % higher
-// clock on this shape than on 32x32x16 at (almost) the same cycles per FLOP (tools/microbench/mfma_shape.hip),
-// and the fused tower is power-limited, so this is the default shape.  A wave's 128 channels x 32 J positions
-// are 8 channel blocks x 2 J position blocks of 16 x 16, one k-step covers K = 32:
-//   T[a][b][r] = channel 16 a + 4 gc + r, position 16 b + lp of the wave's rows
-//   A fragment (weights), block a: row 16 a + lp of the tap's [128][128] image, 16-byte piece ks + koff
-//   B fragment (activations), block b: LDS row of position 16 b + lp (+ the tap's offset), piece ks + koff
-// with, for lane = 16 g + l15:  lp = l15 ^ 4 below 8, l15 from 8 up;  gc = g ^ 1 below 2, g from 2 up;
-// koff = 0, 8, 4, 12 for g = 0..3.  The hardware fixes which lane feeds which MFMA row / column / k slice, not
-// which channel, position or 8-wide k slice that is, and the plain choice (lp = l15, piece 4 ks + g) costs a 2-way
-// bank conflict on every activation read: a ds_read_b128 is served in four groups of 16 lanes, {0-3, 12-15, 20-27},
-// {4-11, 16-19, 28-31} and the same + 32, i.e. half a k slice's lanes with the OTHER half of the next slice's.  On the
-// rotated activation image (17 slots of 16 B per row) the two halves land on disjoint slots only if their rows are
-// complementary sets closed under + 8 and their pieces differ by 8; on the XOR-ed weight image the same holds with
-// ^ 8.  lp sends lanes {0-3, 12-15} to rows {4-7, 12-15} and the rest to {0-3, 8-11}, and slices g, g + 1 of a
-// group read pieces p, p + 8: every group of both reads covers all 16 slots (SQ_LDS_BANK_CONFLICT: 27 % of the
-// LDS cycles before).  A lane still holds four consecutive channels of one position.
+// The convolutions run on v_mfma_f32_16x16x32_{f16,bf16}.  A wave owns 32 J positions (J = 2: 256-row workgroup
+// tiles; J = 1: 128-row tiles for small boards, so that a small batch still fills the chip) x 128 channels =
+// 2 J position blocks x 8 channel tiles of 16 x 16; one k-step covers K = 32 input channels, a tap four k-steps.
+//
+// Operand roles.  The ACTIVATIONS are the MFMA's A operand (rows of D = positions), the WEIGHTS its B operand
+// (columns of D = output channels).  The kernel is power-bound and what the chip draws depends on the data and on
+// the side it enters: about half of a ReLU output is zeros, and zeros in A let a bare loop hold 2.29 GHz where the
+// same zeros in B hold 2.18 (dense weights on the other side; tools/microbench/mfma_operand_power.hip).  With the
+// roles the other way round this kernel took 4.6 % longer.
+//
+// What a lane stands for.  The hardware fixes which lane feeds which row / column / k slice of the MFMA (lane =
+// 16 g + l15: A row l15, B column l15, k slice g; D rows 4 g .. 4 g + 3 of column l15), not which position,
+// channel or 8-wide slice of K that is.  With lrc = l15 ^ 4 below 8 and l15 from 8 up, gc = g ^ 1 below 2 and g
+// from 2 up, koff = 0, 8, 4, 12 for g = 0..3:
+//   A fragment (activations), block b: LDS row of position 16 b + lrc (+ the tap's offset), 16-byte piece ks + koff
+//   B fragment (weights), tile a: row 16 a + lrc of the tap's [128][128] image, piece ks + koff, and that image
+//       row holds output channel 64 (a >> 2) + 4 lrc + (a & 3) (the pack kernel orders the rows so)
+//   T[a][b][r] = position 16 b + 4 gc + r, channel 64 (a >> 2) + 4 lrc + (a & 3)
+// so the four tiles a = 4 q .. 4 q + 3 give a lane FOUR CONSECUTIVE CHANNELS of each of its positions: the
+// epilogue packs them into one 8-byte LDS store, and the 16 lanes of a row fill 128 contiguous bytes.
+// lrc and koff are what makes both fragment reads conflict-free: a ds_read_b128 is served in four groups of 16
+// lanes, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32, i.e. half of one k slice's lanes with the
+// OTHER half of the next slice's.  On the rotated activation image (17 slots of 16 B per row) the two halves land
+// on disjoint slots only if their rows are complementary sets closed under + 8 and their pieces differ by 8; on
+// the XOR-ed weight image the same holds with ^ 8.  lrc sends lanes {0-3, 12-15} to rows {4-7, 12-15} and the rest
+// to {0-3, 8-11}, and slices g, g + 1 of a group read pieces p, p + 8: every group of both reads covers all 16
+// slots (with lrc = l15 and piece 4 ks + g, SQ_LDS_BANK_CONFLICT was 27 % of the LDS cycles).
 // The MFMAs are inline asm with the accumulator tied in an AGPR quad: with the builtin the register allocator
 // copies accumulators around inside the loop.  What the compiler cannot see behind the asm is handled here:
 // wait states between the last MFMAs and the first read of their results, and between the epilogue's writes of
@@ -890,58 +736,54 @@ __device__ __forceinline__ void acc_fence16(AccTile16<J>& T) {
         for (int b = 0; b < 2 * J; ++b) asm volatile("" : "+a"(T[a][b]));
 }
 
+// T = bias[channel]; bl = bias + 4 lrc: tiles 4q .. 4q+3 of a lane hold channels 64 q + 4 lrc + (0..3)
 template <int J>
-__device__ __forceinline__ void fused_bias_init16(AccTile16<J>& T, const float* bptr, int g) {
+__device__ __forceinline__ void fused_bias_init16(AccTile16<J>& T, const float* bl) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const float4 bv = *(const float4*)(bptr + 16 * a + 4 * g);
+    for (int q = 0; q < 2; ++q) {
+        const float4 bv = *(const float4*)(bl + 64 * q);
 #pragma unroll
-        for (int b = 0; b < 2 * J; ++b) { T[a][b][0] = bv.x; T[a][b][1] = bv.y; T[a][b][2] = bv.z; T[a][b][3] = bv.w; }
+        for (int b = 0; b < 2 * J; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { T[4 * q][b][r] = bv.x; T[4 * q + 1][b][r] = bv.y; T[4 * q + 2][b][r] = bv.z; T[4 * q + 3][b][r] = bv.w; }
     }
 }
 
-// fused_epi_hidden / fused_epi_residual in this layout (row0: the lane's position of block 0, + 8 g bytes)
-template <int PR, int J>
-__device__ __forceinline__ void fused_epi_hidden16(AccTile16<J>& Y, const float* next_bias, unsigned char* row0,
-                                                   const float (&caps)[2 * J], int g) {
+// fused_epi_hidden / fused_epi_residual in this layout.  row0: the lane's first position (4 gc of block 0) + 8 lrc bytes;
+// caps[b][r]: the cap of position 16 b + 4 gc + r; bl = next bias + 4 lrc.  One 8-byte store = the four channels
+// 64 q + 4 lrc .. + 3 of one position, taken from four tiles; a 16-lane group fills 128 contiguous bytes of a row.
+template <int PR, int J, bool RESID>
+__device__ __forceinline__ void fused_epi16(AccTile16<J>& T, const float* bl, unsigned char* row0, const float (&caps)[2 * J][4]) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const float4 bv = *(const float4*)(next_bias + 16 * a + 4 * g);
-#pragma unroll
-        for (int b = 0; b < 2 * J; ++b) {
-            const float cap = caps[b];
-            uint2 o;
-            o.x = Prec<PR>::pack2(relu_cap(Y[a][b][0], cap), relu_cap(Y[a][b][1], cap));
-            o.y = Prec<PR>::pack2(relu_cap(Y[a][b][2], cap), relu_cap(Y[a][b][3], cap));
-            *(uint2*)(row0 + b * 16 * A_STRIDE + 32 * a) = o;
-            Y[a][b][0] = bv.x; Y[a][b][1] = bv.y; Y[a][b][2] = bv.z; Y[a][b][3] = bv.w;
-        }
-        if (a & 1) __builtin_amdgcn_sched_barrier(0);      // 32 values at a time: short live ranges
-    }
-}
-template <int PR, int J>
-__device__ __forceinline__ void fused_epi_residual16(AccTile16<J>& X, const float* next_bias, unsigned char* row0,
-                                                     const float (&caps)[2 * J], int g) {
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const float4 bv = *(const float4*)(next_bias + 16 * a + 4 * g);
+    for (int q = 0; q < 2; ++q) {
+        const float4 bv = *(const float4*)(bl + 64 * q);
 #pragma unroll
         for (int b = 0; b < 2 * J; ++b) {
-            const float cap = caps[b];
-            const float r0 = relu_cap(X[a][b][0], cap), r1 = relu_cap(X[a][b][1], cap);
-            const float r2 = relu_cap(X[a][b][2], cap), r3 = relu_cap(X[a][b][3], cap);
-            uint2 o;
-            o.x = Prec<PR>::pack2(r0, r1);
-            o.y = Prec<PR>::pack2(r2, r3);
-            *(uint2*)(row0 + b * 16 * A_STRIDE + 32 * a) = o;
-            X[a][b][0] = r0 + bv.x; X[a][b][1] = r1 + bv.y; X[a][b][2] = r2 + bv.z; X[a][b][3] = r3 + bv.w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float cap = caps[b][r];
+                const float r0 = relu_cap(T[4 * q][b][r], cap), r1 = relu_cap(T[4 * q + 1][b][r], cap);
+                const float r2 = relu_cap(T[4 * q + 2][b][r], cap), r3 = relu_cap(T[4 * q + 3][b][r], cap);
+                uint2 o;
+                o.x = Prec<PR>::pack2(r0, r1);
+                o.y = Prec<PR>::pack2(r2, r3);
+                *(uint2*)(row0 + (16 * b + r) * A_STRIDE + 128 * q) = o;
+                if (RESID) { T[4 * q][b][r] = r0 + bv.x; T[4 * q + 1][b][r] = r1 + bv.y; T[4 * q + 2][b][r] = r2 + bv.z; T[4 * q + 3][b][r] = r3 + bv.w; }
+                else { T[4 * q][b][r] = bv.x; T[4 * q + 1][b][r] = bv.y; T[4 * q + 2][b][r] = bv.z; T[4 * q + 3][b][r] = bv.w; }
+            }
+            __builtin_amdgcn_sched_barrier(0);             // 16 values at a time: short live ranges
         }
-        if (a & 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// One 3x3 convolution accumulated onto `acc`: the weight stream, double buffer, swizzle and hand-over of
-// fused_conv_taps, with four k-steps of 32 per tap.  A k-step is 8 x 2 J MFMAs, channel block major; the
+// One 3x3 convolution (nine taps) accumulated onto `acc`.  Weight chunk g + tap sits in buffer (g + tap) & 1 when
+// the tap starts; chunk g + tap + 1 streams in behind it.  One chunk = one tap = [n=128][k=128] 16-bit = 32 KB,
+// copied global -> LDS by the buffer-addressed LDS DMA (scalar resource + scalar chunk offset + per-lane 32-bit
+// offset, 16 B per lane, no staging registers; the compiler keeps counted s_waitcnt lgkmcnt(N) for the fragment
+// reads while pieces are in flight).  The LDS image is lane-linear, so the bank-conflict fix is an XOR swizzle
+// applied to the SOURCE address and again on the read: 16-byte piece c of row n sits at piece c ^ (n & 15).
+// Four k-steps of 32 per tap; the pipeline runs across tap boundaries: the barrier that hands over the weight
+// buffers sits before the LAST k-step of a tap, whose MFMAs then cover the first fragment reads of the next tap.  A k-step is 8 x 2 J MFMAs, channel block major; the
 // 8 + 2 J fragment reads of the NEXT k-step go one per gap behind its first MFMAs, in the order the next
 // k-step consumes them (activations, then weights by channel block), which leaves the last of them more than
 // a dozen MFMAs to return; the eight 4 KB pieces of the next tap's weights go out in k-steps 0 and 1, in the
@@ -984,7 +826,7 @@ __device__ __forceinline__ void fused_conv_taps16(AccTile16<J>& acc, int g, int 
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const int m = a * NB + b;                // MFMA number inside the k-step
-                    mfma16<PR>(acc[a][b], fw[c][a], fx[c][b]);
+                    mfma16<PR>(acc[a][b], fx[c][b], fw[c][a]);       // activations are the A operand (see AccTile16)
                     if (m < NB) fx[n][m] = *(const u32x4*)(rA + m * 16 * A_STRIDE);
                     else if (m < NB + 8) fw[n][m - NB] = *(const u32x4*)(rB + (m - NB) * 16 * 256);
                     if (ks < 2 && m >= 4 * NB && (m - 4 * NB) % NB == 0) {        // 4 pieces per k-step, NB MFMAs apart
@@ -1008,12 +850,7 @@ __device__ __forceinline__ void fused_conv_taps16(AccTile16<J>& acc, int g, int 
 #ifndef AZ_TOWER_REG_CAP
 #define AZ_TOWER_REG_CAP __attribute__((amdgpu_num_vgpr(224)))
 #endif
-template <int J, int SH> struct TileOf;
-template <int J> struct TileOf<J, 32> { typedef f32x16 type[4][J]; };
-template <int J> struct TileOf<J, 16> { typedef f32x4 type[8][2 * J]; };
-
-// SH: MFMA shape of the convolutions, 16 = v_mfma_f32_16x16x32 (default), 32 = v_mfma_f32_32x32x16
-template <int PR, int J, int SH>
+template <int PR, int J>
 __global__ void __launch_bounds__(256) AZ_TOWER_REG_CAP
 az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
@@ -1034,14 +871,11 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
     const int l15 = lane & 15, gq = lane >> 4;               // 16x16x32 shape: MFMA row / column of the lane, k slice
     const int lrc = l15 < 8 ? l15 ^ 4 : l15;                 // ... the position / channel row it stands for (see AccTile16)
     const int gc = gq < 2 ? gq ^ 1 : gq;                     // ... the group of four channels its accumulators hold
     const int koff = ((gq & 1) << 3) | ((gq & 2) << 1);      // ... the 16-byte piece its k slice starts from
-    constexpr int NPB = SH == 16 ? 2 * J : J;                // position blocks of a wave
-    constexpr int PBS = SH == 16 ? 16 : 32;                  // positions per block
-    const int lpos = SH == 16 ? lrc : l31;                    // this lane's position inside a block
+    constexpr int NPB = 2 * J;                               // 16-position blocks of a wave
     const int b0 = blockIdx.x * bpt;                         // first board of the tile
     const int nb_here = min(bpt, B - b0);
     const int rows_here = nb_here * P;                       // tile rows that belong to boards
@@ -1110,19 +944,21 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();
     TSTAMP(41);
 
-    typename TileOf<J, SH>::type X, Y;   // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
-    if constexpr (SH == 16) fused_bias_init16<J>(X, sBias, gc); else fused_bias_init(X, sBias, h);   // stem bias
+    AccTile16<J> X, Y;                   // X: fp32 residual stream = accumulator of every second convolution; Y: of every first
+    fused_bias_init16<J>(X, sBias + 4 * lrc);                // stem bias
 
-    // which of this lane's positions are real board cells
-    float keepcap[NPB];
+    // which of this lane's positions (16 b + 4 gc + r of the wave's rows) are real board cells
+    float cap16[NPB][4];
 #pragma unroll
-    for (int j = 0; j < NPB; ++j) {
-        const int r = PW * wv + PBS * j + lpos;
-        const int p = r % P;
-        keepcap[j] = (r < rows_here && (p / W) < N && (p % W) < N) ? Prec<PR>::cap() : 0.f;
-    }
+    for (int b = 0; b < NPB; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = PW * wv + 16 * b + 4 * gc + r4;
+            const int p = r % P;
+            cap16[b][r4] = (r < rows_here && (p / W) < N && (p % W) < N) ? Prec<PR>::cap() : 0.f;
+        }
 
-    if constexpr (SH == 16) {
+    {
         // stem: the im2col tile is exactly one k-step of 32
         u32x4 xb[NPB], wa[8];
 #pragma unroll
@@ -1134,35 +970,16 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b = 0; b < NPB; ++b) mfma16<PR>(X[a][b], wa[a], xb[b]);
+            for (int b = 0; b < NPB; ++b) mfma16<PR>(X[a][b], xb[b], wa[a]);
         asm volatile("s_nop 15\n\ts_nop 7");
         acc_fence16<J>(X);
-    } else
-    // stem: 2 k-steps of 16 over the im2col tile
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        typename Prec<PR>::vec xb[J], wa[4];
-#pragma unroll
-        for (int j = 0; j < J; ++j) xb[j] = *(const typename Prec<PR>::vec*)(sI + (PW * wv + 32 * j + l31) * I_STRIDE + ks * 32 + h * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wa[i] = *(const typename Prec<PR>::vec*)(sW + (32 * i + l31) * I_STRIDE + ks * 32 + h * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < J; ++j)
-                X[i][j] = Prec<PR>::mfma(wa[i], xb[j], X[i][j]);
     }
     __syncthreads();                                         // every wave is done with sI / sW
     TSTAMP(42);
     // bias table: [0] stem, [1 + L] convolution L.  Block b = convolutions 2b (onto Y) and 2b+1 (onto X).
-    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + lpos) * A_STRIDE + 8 * (SH == 16 ? gc : h);
-    if constexpr (SH == 16) {
-        fused_epi_residual16<PR, J>(X, sBias + 2 * 128, row0, keepcap, gc);
-        fused_bias_init16<J>(Y, sBias + 1 * 128, gc);
-    } else {
-        fused_epi_residual<PR, J>(X, sBias + 2 * 128, row0, keepcap, h);
-        fused_bias_init(Y, sBias + 1 * 128, h);
-    }
+    unsigned char* const row0 = sA + (size_t)(Gd + PW * wv + 4 * gc) * A_STRIDE + 8 * lrc;
+    fused_epi16<PR, J, true>(X, sBias + 2 * 128 + 4 * lrc, row0, cap16);
+    fused_bias_init16<J>(Y, sBias + 1 * 128 + 4 * lrc);
 
     // weight stream set-up (see fused_conv_taps): piece p (0..7) of a chunk is 256 lanes x 16 B;
     // lane's piece index q = p*256 + tid -> LDS row q>>4 = p*16 + (tid>>4), physical piece tid&15,
@@ -1182,24 +999,20 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     __syncthreads();
     TSTAMP(1);
 
-    const int posrow0 = Gd + PW * wv + lpos;
+    const int posrow0 = Gd + PW * wv + lrc;
     const int n_blocks = n_layers >> 1;
     for (int b = 0; b < n_blocks; ++b) {
         // next block's biases; after the last block X restarts from the zero row: the heads read relu(x) itself
         const int nb1 = min(3 + 2 * b, n_layers), nb2 = b + 1 < n_blocks ? 4 + 2 * b : n_layers + 1;
-        if constexpr (SH == 16) fused_conv_taps16<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, koff, lrc);
-        else fused_conv_taps<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
+        fused_conv_taps16<PR, J>(Y, 18 * b, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, koff, lrc);
         // (the barrier before the last k-step: all waves have finished reading this layer's input)
         TSTAMP(2 + 4 * b);
-        if constexpr (SH == 16) fused_epi_hidden16<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, gc);
-        else fused_epi_hidden<PR, J>(Y, sBias + nb1 * 128, row0, keepcap, h);
+        fused_epi16<PR, J, false>(Y, sBias + nb1 * 128 + 4 * lrc, row0, cap16);
         __syncthreads();
         TSTAMP(3 + 4 * b);
-        if constexpr (SH == 16) fused_conv_taps16<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, koff, lrc);
-        else fused_conv_taps<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, h, l31);
+        fused_conv_taps16<PR, J>(X, 18 * b + 9, total, sA, sB, wrsrc, st_off, st_dst, posrow0, W, koff, lrc);
         TSTAMP(4 + 4 * b);
-        if constexpr (SH == 16) fused_epi_residual16<PR, J>(X, sBias + nb2 * 128, row0, keepcap, gc);
-        else fused_epi_residual<PR, J>(X, sBias + nb2 * 128, row0, keepcap, h);
+        fused_epi16<PR, J, true>(X, sBias + nb2 * 128 + 4 * lrc, row0, cap16);
         __syncthreads();
         TSTAMP(5 + 4 * b);
     }
@@ -1224,69 +1037,45 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         const int pp = r % P, py = pp / W, px = pp % W;
         const bool cell = r < rows_here && py < N && px < N;
         // Both 1x1 convolutions straight from the fp32 residual tile X (= relu(x), the last epilogue added a
-        // zero bias): a lane holds 64 of the 128 channels of each of its J positions, the other half sits in
-        // lane ^ 32.  Nothing is rounded to 16 bits between the last ResBlock and the heads.
-        f32x2 spv[NPB];
+        // zero bias).  Nothing is rounded to 16 bits between the last ResBlock and the heads.
+        {
+            // a lane holds 8 of the 128 channels (64 q + 4 lrc + 0..3) of each of its 4 x 2 J positions; the other
+            // fifteen lanes of its 16-lane row hold the rest
+            f32x2 sp16[NPB][4];
 #pragma unroll
-        for (int j = 0; j < NPB; ++j) spv[j] = (f32x2){0.f, 0.f};
-        if constexpr (SH == 16) {
-            // a lane holds 32 of the 128 channels of each of its positions (16 a + 4 gc + r); lanes ^ 16, ^ 32 the rest
+            for (int b = 0; b < NPB; ++b)
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const float4 w01 = *(const float4*)(hp + 2 * (16 * a + 4 * gc));
-                const float4 w23 = *(const float4*)(hp + 2 * (16 * a + 4 * gc) + 4);
+                for (int r = 0; r < 4; ++r) sp16[b][r] = (f32x2){0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < NPB; ++j) {
-                    const float x0 = X[a][j][0], x1 = X[a][j][1], x2 = X[a][j][2], x3 = X[a][j][3];
-                    spv[j] += (f32x2){x0, x0} * (f32x2){w01.x, w01.y};
-                    spv[j] += (f32x2){x1, x1} * (f32x2){w01.z, w01.w};
-                    spv[j] += (f32x2){x2, x2} * (f32x2){w23.x, w23.y};
-                    spv[j] += (f32x2){x3, x3} * (f32x2){w23.z, w23.w};
-                }
+            for (int q = 0; q < 2; ++q) {
+                const float4 w01 = *(const float4*)(hp + 2 * (64 * q + 4 * lrc));          // {wp, wv} of channels c, c + 1
+                const float4 w23 = *(const float4*)(hp + 2 * (64 * q + 4 * lrc) + 4);      // c + 2, c + 3
+#pragma unroll
+                for (int b = 0; b < NPB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x0 = X[4 * q][b][r], x1 = X[4 * q + 1][b][r], x2 = X[4 * q + 2][b][r], x3 = X[4 * q + 3][b][r];
+                        sp16[b][r] += (f32x2){x0, x0} * (f32x2){w01.x, w01.y};
+                        sp16[b][r] += (f32x2){x1, x1} * (f32x2){w01.z, w01.w};
+                        sp16[b][r] += (f32x2){x2, x2} * (f32x2){w23.x, w23.y};
+                        sp16[b][r] += (f32x2){x3, x3} * (f32x2){w23.z, w23.w};
+                    }
             }
             TSTAMP(43);
 #pragma unroll
-            for (int j = 0; j < NPB; ++j) {
-                float lp = spv[j].x + __shfl_xor(spv[j].x, 16, 64);
-                float lv = spv[j].y + __shfl_xor(spv[j].y, 16, 64);
-                lp += __shfl_xor(lp, 32, 64);
-                lv += __shfl_xor(lv, 32, 64);
-                if (gq == 0) {
-                    const int row = PW * wv + 16 * j + lrc;
-                    const bool real = keepcap[j] != 0.f;
-                    s_logit[row] = real ? lp + bp : -3.4e38f;
-                    s_u[row] = real ? fmaxf(lv + bvv, 0.f) : 0.f;
+            for (int b = 0; b < NPB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sp_ = sp16[b][r].x, sv_ = sp16[b][r].y;
+#pragma unroll
+                    for (int o2 = 1; o2 < 16; o2 <<= 1) { sp_ += __shfl_xor(sp_, o2, 64); sv_ += __shfl_xor(sv_, o2, 64); }
+                    if (l15 == 0) {
+                        const int row = PW * wv + 16 * b + 4 * gc + r;
+                        const bool real = cap16[b][r] != 0.f;
+                        s_logit[row] = real ? sp_ + bp : -3.4e38f;
+                        s_u[row] = real ? fmaxf(sv_ + bvv, 0.f) : 0.f;
+                    }
                 }
-            }
-        } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w01 = *(const float4*)(hp + 2 * (32 * i + 8 * q + 4 * h));       // {wp, wv} of channels c, c+1
-                const float4 w23 = *(const float4*)(hp + 2 * (32 * i + 8 * q + 4 * h) + 4);   // c+2, c+3
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const float x0 = X[i][j][4 * q + 0], x1 = X[i][j][4 * q + 1];
-                    const float x2 = X[i][j][4 * q + 2], x3 = X[i][j][4 * q + 3];
-                    spv[j] += (f32x2){x0, x0} * (f32x2){w01.x, w01.y};
-                    spv[j] += (f32x2){x1, x1} * (f32x2){w01.z, w01.w};
-                    spv[j] += (f32x2){x2, x2} * (f32x2){w23.x, w23.y};
-                    spv[j] += (f32x2){x3, x3} * (f32x2){w23.z, w23.w};
-                }
-            }
-        TSTAMP(43);
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const float lp = spv[j].x + __shfl_xor(spv[j].x, 32, 64);
-            const float lv = spv[j].y + __shfl_xor(spv[j].y, 32, 64);
-            if (h == 0) {
-                const int row = PW * wv + 32 * j + l31;
-                const bool real = keepcap[j] != 0.f;
-                s_logit[row] = real ? lp + bp : -3.4e38f;
-                s_u[row] = real ? fmaxf(lv + bvv, 0.f) : 0.f;
-            }
-        }
         }
         if (TM < 256 && tid < 256 - TM) { s_logit[TM + tid] = -3.4e38f; s_u[TM + tid] = 0.f; }
         for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
@@ -1535,10 +1324,8 @@ extern "C" int az_tower_configure(void) {
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
     SETA(az_heads_kernel<0>, 128 * 1024); SETA(az_heads_kernel<1>, 128 * 1024);
-    SETA((az_tower_fused_kernel<0, 2, 32>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2, 32>), 160 * 1024);
-    SETA((az_tower_fused_kernel<0, 1, 32>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1, 32>), 160 * 1024);
-    SETA((az_tower_fused_kernel<0, 2, 16>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2, 16>), 160 * 1024);
-    SETA((az_tower_fused_kernel<0, 1, 16>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1, 16>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
+    SETA((az_tower_fused_kernel<0, 1>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1>), 160 * 1024);
 #undef SETA
     return (int)e;
 }
@@ -1588,7 +1375,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
                                       const float* stem_b, const unsigned short* wpk, const float* bias,
                                       const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers) {
     const int P = (N + 1) * (N + 1);
-    // Tile height: 256 rows (two 32-position blocks per wave), or 128 rows where a whole board fits in 128
+    // Tile height: 256 rows (four 16-position blocks per wave), or 128 rows where a whole board fits in 128
     // and the batch is too small to fill the chip with 256-row tiles.  A 128-row tile does half the MFMA
     // work per weight byte, so it costs ~0.6 of a 256-row tile, not 0.5: take it when it saves tile rounds.
     int rows = TILE_M;
@@ -1602,13 +1389,10 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     const int bpt = rows / P;
     const int tiles = (B + bpt - 1) / bpt;
     const size_t sm = az_tower_fused_lds_bytes(N, n_layers, rows);
-    const char* shape = getenv("AZ_MFMA_SHAPE");             // "32": the 32x32x16 build of the kernel (A/B and tests)
-    const bool s32 = shape && atoi(shape) == 32;
 #define FUSED_ARGS dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt
-#define FUSED_LAUNCH(J_, SH_) do { if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, J_, SH_>), FUSED_ARGS); \
-                                   else hipLaunchKernelGGL((az_tower_fused_kernel<0, J_, SH_>), FUSED_ARGS); } while (0)
-    if (rows == 128) { if (s32) FUSED_LAUNCH(1, 32); else FUSED_LAUNCH(1, 16); }
-    else { if (s32) FUSED_LAUNCH(2, 32); else FUSED_LAUNCH(2, 16); }
+#define FUSED_LAUNCH(J_) do { if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, J_>), FUSED_ARGS); \
+                              else hipLaunchKernelGGL((az_tower_fused_kernel<0, J_>), FUSED_ARGS); } while (0)
+    if (rows == 128) FUSED_LAUNCH(1); else FUSED_LAUNCH(2);
 #undef FUSED_LAUNCH
 #undef FUSED_ARGS
 }

@@ -19,6 +19,11 @@ __device__ __forceinline__ unsigned short w_to16(float x, int prec) {
     return (unsigned short)(u >> 16);
 }
 
+// Row of output channel co in the fused kernel's weight images: its 16x16x32 tiles take weights as the B operand
+// with lane l of tile a = 4 q + j standing for channel 64 q + 4 l + j, so that the four tiles of a quad give a lane
+// four consecutive channels of a position (one 8-byte store).  Image row 16 a + l holds that channel.
+__device__ __forceinline__ int fused_row(int co) { return (co & ~63) | ((co & 3) << 4) | ((co >> 2) & 15); }
+
 __device__ __forceinline__ double bn_scale(const float* bn, int C, int ch) {     // bn: weight, bias, mean, var
     return (double)bn[ch] / sqrt((double)bn[3 * C + ch] + 1e-5);
 }
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(256) az_fold_conv_kernel(AzFoldArgs a) {
         const int ci = e / 9, tap = e % 9;
         const unsigned short v = w_to16((float)(w[(size_t)co * C * 9 + e] * s), a.prec);
         if (a.fused)                                          // one 32 KB chunk per tap: [layer][tap][n][k]
-            a.conv_wf[(((size_t)L * 9 + tap) * 128 + co) * 128 + ci] = v;
+            a.conv_wf[(((size_t)L * 9 + tap) * 128 + fused_row(co)) * 128 + ci] = v;
         else {                                                // [layer][nb][sc][tap][n][k]
             const size_t chunk = ((size_t)(co / 128) * nblk + ci / 128) * 9 + tap;
             a.conv_w[(size_t)L * a.conv_layer_elems + chunk * (128 * 128) + (size_t)(co % 128) * 128 + ci % 128] = v;
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256) az_fold_small_kernel(AzFoldArgs a) {
     for (int e = threadIdx.x; e < C * KW; e += 256) {
         const int co = e / KW, k = e % KW;
         const float f = (float)(sw[e] * bn_scale(sbn, C, co));
-        if (a.fused) a.stem_wbf[(size_t)co * 32 + k] = w_to16(f, a.prec);
+        if (a.fused) a.stem_wbf[(size_t)fused_row(co) * 32 + k] = w_to16(f, a.prec);
         else a.stem_w[e] = f;
     }
     for (int co = threadIdx.x; co < C; co += 256) a.stem_b[co] = bn_bias(sbn, C, co, sb[co], bn_scale(sbn, C, co));

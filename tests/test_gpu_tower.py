@@ -248,29 +248,6 @@ def test_weights_are_folded_on_the_device_and_bad_blobs_are_refused(monkeypatch,
     assert np.array_equal(p3, p1) and np.array_equal(v3, v1)
 
 
-@pytest.mark.parametrize("N,B", [(15, 20), (9, 300), (5, 33)])
-def test_fused_tower_32x32x16_build_matches_the_default_16x16x32_build(monkeypatch, N, B):
-    """The fused kernel exists on both MFMA shapes (16x16x32 is the default, AZ_MFMA_SHAPE=32 selects the
-    32x32x16 build): same operands, same fp32 accumulation per output, different summation grouping."""
-    import torch
-    torch.set_num_threads(8)
-    Cs = synth.NETCONFIG2
-    blob = synth.make_blob(N, 3, Cs, 81 + N, phead_gain=10.0, fc2_gain=5.0)
-    boards = synth.random_boards(B, N, seed=80 + N)
-    eng = capi.Engine(N, min(N, 5), B, Cs=Cs)
-    assert eng.tower_is_fused()
-    eng.load_weights(blob)
-    p16, v16 = eng.tower_forward(boards)
-    monkeypatch.setenv("AZ_MFMA_SHAPE", "32")
-    p32, v32 = eng.tower_forward(boards)
-    assert not np.array_equal(p16, p32) or N == 5
-    assert np.abs(p16 - p32).max() < 2e-4 and np.abs(v16 - v32).max() < 2e-4
-    with torch.no_grad():
-        rp, rv = torch_reference(N, Cs, blob, boards)
-    for p, v in ((p16, v16), (p32, v32)):
-        assert np.abs(p - rp).max() < TOL and np.abs(v - rv).max() < TOL
-
-
 @pytest.mark.parametrize("prec", [capi.AZ_PREC_FP16, capi.AZ_PREC_BF16], ids=["fp16", "bf16"])
 def test_blokus_shaped_tower_matches_torch_fp32(prec):
     """20x20 board, 5 input planes, 91 policy channels (softmax over 36 400 entries), a four-entry value head:

@@ -1,0 +1,76 @@
+// Does the MFMA's power (hence the clock the chip holds) depend on WHICH operand carries the zeros / the short
+// mantissas?  Bare v_mfma_f32_16x16x32_f16 loops, operands in registers, 128 x 64 wave tile, one wave per SIMD on
+// every CU; A = src0 (the tower feeds weights here), B = src1 (activations).  Variants of the data:
+//   dense   random fp16 in [-1, 1) with full mantissas      sparse  the same with every other 16-bit element zero
+//   short   random fp16 with the low 6 mantissa bits zero
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ void __launch_bounds__(256) k16(const u32x4* __restrict__ ra, const u32x4* __restrict__ rb, float* out,
+                                           unsigned long long* ts, int iters) {
+    const int tid = threadIdx.x;
+    u32x4 A[8], B[4];
+    for (int i = 0; i < 8; ++i) A[i] = ra[tid * 8 + i];
+    for (int j = 0; j < 4; ++j) B[j] = rb[tid * 4 + j];
+    f32x4 acc[32];
+    for (int a = 0; a < 32; ++a) { acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[a])); }
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i * 4 + j]) : "v"(A[i]), "v"(B[j]));
+    }
+    asm volatile("s_nop 15\n\ts_nop 7");
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int a = 0; a < 32; ++a) { asm volatile("" : "+a"(acc[a])); for (int r = 0; r < 4; ++r) s += acc[a][r]; }
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0 && blockIdx.x == 17) { ts[0] = t1 - t0; ts[1] = r1 - r0; }
+}
+
+static void fill(unsigned* h, int n, int kind) {
+    for (int i = 0; i < n; ++i) {
+        unsigned w = 0;
+        for (int half = 0; half < 2; ++half) {
+            const unsigned a = rand();
+            unsigned v = ((a & 1) << 15) | ((13u + (a >> 1 & 1)) << 10) | (a >> 2 & 0x3FF);      // +-[0.25, 1)
+            if (kind == 1 && half == 1) v = 0;                                               // sparse: every other element zero
+            if (kind == 2) v &= ~0x3Fu;                                                      // short mantissa
+            w |= v << (16 * half);
+        }
+        h[i] = w;
+    }
+}
+
+int main() {
+    const int iters = 20000, blocks = 256;
+    u32x4 *ra, *rb; float* out; unsigned long long* ts;
+    CHK(hipMalloc(&ra, 256 * 8 * 16)); CHK(hipMalloc(&rb, 256 * 4 * 16)); CHK(hipMalloc(&out, blocks * 256 * 4)); CHK(hipMalloc(&ts, 64));
+    unsigned* ha = (unsigned*)malloc(256 * 8 * 16); unsigned* hb = (unsigned*)malloc(256 * 4 * 16);
+    const char* names[3] = {"dense", "sparse", "short"};
+    for (int ka = 0; ka < 3; ++ka)
+        for (int kb = 0; kb < 3; ++kb) {
+            srand(1);
+            fill(ha, 256 * 8 * 4, ka); fill(hb, 256 * 4 * 4, kb);
+            CHK(hipMemcpy(ra, ha, 256 * 8 * 16, hipMemcpyHostToDevice)); CHK(hipMemcpy(rb, hb, 256 * 4 * 16, hipMemcpyHostToDevice));
+            float best = 1e9f; double clk = 0;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+                CHK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, ra, rb, out, ts, iters);
+                CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                unsigned long long t[2]; CHK(hipMemcpy(t, ts, 16, hipMemcpyDeviceToHost));
+                if (rep && ms < best) { best = ms; clk = (double)t[0] / t[1] * 0.1; }
+            }
+            const double flop = (double)blocks * 4 * iters * 128.0 * 64 * 32 * 2;
+            printf("A %-6s B %-6s: %.3f ms, %.0f TFLOP/s, clock %.3f GHz\n", names[ka], names[kb], best, flop / (best * 1e-3) / 1e12, clk);
+        }
+    return 0;
+}
