@@ -60,6 +60,7 @@ struct az_ctx {
     unsigned short* stem_wbf = nullptr;                   // [128][32] bf16, fused path
     unsigned short* conv_wf = nullptr;                    // [layer][tap][n=128][k=128] bf16, fused path
     bool fused = false;                                   // whole tower in one launch
+    int conv_kind = 0;                                    // per-layer convolution kernel (az_conv_kind), fixed at creation
     int prec = 0;                                         // 0 bf16, 1 fp16 operands
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
@@ -227,6 +228,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         // layers still fits beside it (160 KB per CU); otherwise one launch per convolution
         c->fused = mnk_shape && c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED") &&
                    az_tower_fused_lds_bytes(N, 2 * c->num_res, 256) <= 160 * 1024;
+        c->conv_kind = az_conv_kind();
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
         AZCHK(dalloc(c, &c->stem_b, c->C_pad));
         AZCHK(dalloc(c, &c->conv_b, (size_t)2 * c->num_res * c->C_pad));
@@ -302,7 +304,7 @@ static int load_weights_staged(az_ctx* c) {
     memset(&a, 0, sizeof a);
     a.blob = c->blob_stage; a.n_floats = az_weights_size(c);
     a.N = N; a.A = A; a.C = C; a.Cp = c->C_pad; a.nres = c->num_res;
-    a.fused = c->fused ? 1 : 0; a.prec = c->prec;
+    a.fused = c->fused ? 1 : 0; a.prec = c->prec; a.layer16 = c->conv_kind == 0;
     a.c_in = c->c_in; a.c_out = c->c_out; a.vd = c->vd;
     size_t o = 0;                                            // module registration order: CBlock, PHead, VHead, RBlock_i
     a.off_stem_w = o; o += (size_t)C * c->c_in * 9 + C;
@@ -369,10 +371,10 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
         bool on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
         on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
         prof_end(c, on, c->stream);
     }
     az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd);

@@ -10,7 +10,8 @@ size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows);   // dynamic LDS
 
 void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
                     const float* bias, int B, int N, int C_pad, int Gd, int c_in);
-void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
+int  az_conv_kind(void);                                          // per-layer convolution kernel (0, 1, 2), from the environment
+void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
                        float* resid, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu);
 void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,

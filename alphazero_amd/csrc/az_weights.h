@@ -12,6 +12,7 @@ struct AzFoldArgs {
     int c_in, c_out, vd;        // input planes, policy channels, value entries
     int fused;                  // 1: images of az_tower_fused_kernel, 0: of the per-layer kernels
     int prec;                   // 0 bf16, 1 fp16 operands
+    int layer16;                // per-layer path: rows of each 128-channel block in the order of the 16x16x32 kernel
     size_t off_stem_w;          // CBlock.conv.weight [C][c_in][3][3], then bias [C]
     size_t off_stem_bn;         // CBlock.bn weight, bias, running_mean, running_var [C] each
     size_t off_pc, off_vc;      // PHead.conv: weight [c_out][C], bias [c_out]; VHead.conv: weight [C], bias

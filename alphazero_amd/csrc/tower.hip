@@ -5,10 +5,12 @@
 //                     launch, activations resident in LDS (C <= 128, (N+1)^2 <= 256)
 //   az_stem_kernel    ConvBlock (network.hpp:15-17): 3x3 conv on the u8 planes,
 //                     BN folded, ReLU; fp32 VALU                       } per-layer
-//   az_conv3x3_t256_kernel, az_conv3x3_t128_kernel                      } path for
-//                     ResBlock convolutions (network.hpp:32-38) as      } wider or
-//                     implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}:  } larger
-//                     D[ch][pos] = sum_k W[ch][k] X[k][pos]             } shapes
+//   az_conv3x3_t256s_kernel (default), az_conv3x3_t256_kernel,          } path for
+//   az_conv3x3_t128_kernel                                              } wider or
+//                     ResBlock convolutions (network.hpp:32-38) as      } larger
+//                     implicit GEMM: t256s on v_mfma_f32_16x16x32 with  } shapes
+//                     D[pos][ch] = sum_k X[pos][k] W[ch][k], the other  }
+//                     two on v_mfma_f32_32x32x16 with D[ch][pos]        }
 //   az_heads_kernel   PolicyHead + ValueHead (network.hpp:51-60,75-83)  }
 //
 // Activation layout in HBM: bf16 rows [guard + M_pad + guard][C_pad]; one row
@@ -653,6 +655,299 @@ az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* __
                 }
                 *slot = o;
             }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = tid; i < T4_M * 16; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sO + r * 256 + ((c ^ (r & 15)) << 4));
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int PR>
+__device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& b);
+// Which of the 32 consecutive raster rows from m are cells of a board (bit k: row m + k): one walk over the
+// raster with wave-uniform arguments, so it runs on the scalar unit.
+__device__ __forceinline__ unsigned t4_real_mask(int m, int M, int P, int W, int N) {
+    const int pp = m % P;
+    int y = pp / W, x = pp - y * W;
+    unsigned mask = 0u;
+    for (int k = 0; k < 32; ++k) {
+        if (m + k < M && y < N && x < N) mask |= 1u << k;
+        if (++x == W) { x = 0; if (++y == W) y = 0; }
+    }
+    return mask;
+}
+
+// The 256-row kernel above on v_mfma_f32_16x16x32 with the activations as the A operand: the chip holds a higher
+// clock on this shape and with the zeros (ReLU outputs, padding) in A (tools/microbench/mfma_operand_power.hip).
+// Same tiles, LDS images, weight stream and slab handling; what changes is the k-step (two of 32 per chunk, 32 MFMAs
+// on 4 activation + 8 weight fragments), the accumulator layout and with it the two epilogues, and the order of the
+// weight image's rows (AzFoldArgs::layer16: row 16 a + l of a 128-channel block holds channel 64 (a >> 2) + 4 l + (a & 3)).
+template <int PR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                       float* resid /* fp32 residual stream, updated in place; null: none */, const unsigned short* __restrict__ wpk,
+                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu, int xcd_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = N + 1, P = W * W;
+    const int rows_total = n_tiles * T4_M + 2 * Gd;          // rows of the activation buffers
+    const int slab_rows = t4_slab_rows(Gd);
+    unsigned char* sW = smem;                                // 2 x W2_BYTES
+    unsigned char* sA = smem + 2 * W2_BYTES;                 // slab_rows x 128 B; the epilogue image (64 KB) starts at smem
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int l15 = lane & 15, gq = lane >> 4;               // MFMA row / column of the lane, k slice
+    const int lrc = l15 < 8 ? l15 ^ 4 : l15;                 // the position / weight-image row it stands for (see AccTile16)
+    const int gc = gq < 2 ? gq ^ 1 : gq;                     // its accumulators: positions 4 gc .. 4 gc + 3 of a block
+    const int kpc = ((gq & 1) << 2) | (gq >> 1);             // 16-byte piece of its k slice in k-step 0 (0, 4, 1, 5); + 2 in k-step 1
+    // Workgroups go to the eight XCDs round robin by their linear index, each XCD with an L2 of its own.  Index
+    // -> (tile, output-channel block) so that an XCD works through one contiguous eighth of the tiles with the
+    // channel blocks of a tile back to back: the second block finds the tile's input rows in that L2, and so does
+    // the next tile for the halo rows it shares.  AZ_T256_PLAIN_ORDER (host) keeps the plain (x = tile, y = block) order.
+    int tile_i = blockIdx.x, nb = blockIdx.y;
+    if (gridDim.y == 1 && xcd_tiles > 0) {
+        const int n_nb = C_pad / 128;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nb = slot % n_nb;
+        tile_i = xcd * xcd_tiles + slot / n_nb;
+        if (slot / n_nb >= xcd_tiles || tile_i >= n_tiles) return;
+    }
+    const int m0 = tile_i * T4_M;
+    const int n_sc = C_pad / 128;
+    const int n_kc = C_pad / 64;
+    const int total = n_kc * 9;                              // (slice, tap) chunks
+
+    // acc[a][b][r]: position 64 wv + 16 b + 4 gc + r, channel 64 (a >> 2) + 4 lrc + (a & 3) of the block
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weights: chunk t = kc*9 + tap lives in the packed image at ((nb*n_sc + kc/2)*9 + tap) * 32 KB, columns
+    // [64*(kc&1), +64) of every 256-byte row; piece q = it*256 + tid of a chunk: LDS row it*32 + (tid >> 3),
+    // physical piece tid & 7 = logical piece ^ ((row >> 1) & 7)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(wpk + (size_t)nb * n_sc * 9 * (128 * 128)), 0, n_sc * 9 * (128 * 128 * 2), 0x00020000);
+    const unsigned w_voff = (unsigned)((tid >> 3) * 256 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4));
+    unsigned char* const w_dst = sW + wvu * 1024;
+#define CHUNK_SRC4(t_) ((((t_) / 9 >> 1) * 9 + (t_) % 9) * (128 * 128 * 2) + (((t_) / 9) & 1) * 128)
+#define STAGE_W4(t_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+        wrsrc, (lds_void*)(w_dst + ((t_) & 1) * W2_BYTES + (it_) * 4096), 16, w_voff, CHUNK_SRC4(t_) + (it_) * 8192, 0, 0)
+    // slab: DMA q covers rows 8q .. 8q+7 (lane: row 8q + (lane >> 3), physical piece lane & 7); wave w issues
+    // q = w, w+4, ..., so (row >> 1) & 7 = 4 (w & 1) + (lane >> 4) is a per-lane constant
+    const size_t a_left = (size_t)(rows_total - m0) * C_pad * 2;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(in + (size_t)m0 * C_pad), 0, (int)(a_left < 0x7FFFFFFFull ? a_left : 0x7FFFFFFFull), 0x00020000);
+    const unsigned a_voff = (unsigned)((lane >> 3) * C_pad * 2 + (((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7)) << 4));
+    const int n_q = slab_rows / 8;
+#define STAGE_A4(kc_) do { \
+        for (int q_ = wvu; q_ < n_q; q_ += 4) \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sA + q_ * 1024), 16, \
+                                                     a_voff, q_ * 8 * C_pad * 2 + (kc_) * 128, 0, 0); \
+    } while (0)
+
+#pragma unroll
+    for (int it = 0; it < 4; ++it) STAGE_W4(0, it);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) STAGE_W4(1, it);          // total >= 18: chunk 1 always exists
+    STAGE_A4(0);
+    AZ_DMA_LANDED();
+    __syncthreads();
+
+    // Fragments: activations = the MFMA's A operand, weights = B (see AccTile16 for why and for the lane labels).
+    // Slab and weight images have 128-byte rows (64 k = 8 pieces, piece c of row r at c ^ ((r >> 1) & 7)); the two
+    // k slices that share a ds_read_b128 lane group read pieces 4 apart and rows that are complementary sets closed
+    // under + 8, so every group covers 16 distinct slots.  A chunk is two k-steps of 32.  The four activation
+    // fragments are double-buffered; a weight fragment is refilled in place right behind its tile's last MFMA
+    // (tile-major order: its next use is 28 MFMAs away), which keeps the kernel inside 256 registers.
+    const int s_base = Gd + 64 * wv + lrc;                   // slab row of this lane's position in block 0
+    const int swzW = (lrc >> 1) & 7;
+    const unsigned char* const wrow = sW + lrc * 128;
+    u32x4 fx[2][4], fw[8];
+    {
+        const int s0 = s_base - W - 1;                       // tap 0
+        const int sz = (s0 >> 1) & 7;
+        const unsigned char* bX = sA + s0 * 128 + ((kpc ^ sz) << 4);
+        const unsigned char* bW = wrow + ((kpc ^ swzW) << 4);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fx[0][b] = *(const u32x4*)(bX + b * 2048);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) fw[a] = *(const u32x4*)(bW + a * 2048);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+a"(acc[a][b]));
+    asm volatile("s_nop 7");
+    for (int t = 0; t < total; ++t) {
+        const int kc = t / 9, tap = t - 9 * kc;
+        const int tn_ = t + 1 < total ? t + 1 : t;
+        const int ntap = tn_ - 9 * (tn_ / 9);
+        const int s0 = s_base + (tap / 3 - 1) * W + (tap % 3 - 1);
+        const int ns0 = s_base + (ntap / 3 - 1) * W + (ntap % 3 - 1);
+        const int sz = (s0 >> 1) & 7, nsz = (ns0 >> 1) & 7;
+        const unsigned char* bX = sA + s0 * 128;
+        const unsigned char* nX = sA + ns0 * 128;
+        const unsigned char* bW = wrow + (t & 1) * W2_BYTES;
+        const unsigned char* nW = wrow + ((t + 1) & 1) * W2_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks, n = ks ^ 1;
+            const unsigned char* rX = ks == 0 ? bX + (((kpc + 2) ^ sz) << 4) : nX + ((kpc ^ nsz) << 4);
+            const unsigned char* rW = ks == 0 ? bW + (((kpc + 2) ^ swzW) << 4) : nW + ((kpc ^ swzW) << 4);
+            if (ks == 1) {
+                // hand-over: every wave holds its last fragments of this chunk, the next chunk has landed
+                AZ_DMA_LANDED();
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = 4 * a + b;
+                    mfma16<PR>(acc[a][b], fx[c][b], fw[a]);
+                    if (b == 3) fw[a] = *(const u32x4*)(rW + a * 2048);
+                    if (m == 0 || m == 1 || m == 2 || m == 5) fx[n][m < 3 ? m : 3] = *(const u32x4*)(rX + (m < 3 ? m : 3) * 2048);
+                    if (ks == 1 && t + 2 < total && m >= 16 && (m & 3) == 0) STAGE_W4(t + 2, (m - 16) >> 2);
+                }
+        }
+        if (tap == 8 && t + 1 < total) {
+            // slice boundary: the slab is single-buffered.  The activation fragments just prefetched came from
+            // the old slab (harmless, dropped); reload the slab -- the co-resident workgroup has the MFMA
+            // pipes meanwhile -- and read them again.  The weight fragments are already those of chunk t + 1.
+            __syncthreads();                                 // every wave is done with the slab
+            STAGE_A4(kc + 1);
+            AZ_DMA_LANDED();
+            __syncthreads();
+            const unsigned char* rX = nX + ((kpc ^ nsz) << 4);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fx[0][b] = *(const u32x4*)(rX + b * 2048);
+        }
+    }
+#undef STAGE_W4
+#undef STAGE_A4
+#undef CHUNK_SRC4
+    asm volatile("s_nop 15\n\ts_nop 7");                     // last MFMAs -> first read of their results
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+a"(acc[a][b]));
+    __syncthreads();                                         // all waves done with the buffers: LDS becomes the output image
+
+    if (resid) {
+        // Second convolution of a ResBlock: x = relu(conv + bias + residual) with the residual stream in fp32
+        // (network.hpp:36 in the reference's own precision; only the copy that feeds the next convolution is
+        // rounded to 16 bits).  Two passes of 128 tile rows; a wave handles its own 32 rows per pass end to end
+        // (rows 64 wv + 32 p + [0, 32) of the tile = rows 32 wv + [0, 32) of the LDS image), so the passes need
+        // no hand-over between waves.  Image: fp32 [128 rows][128 ch], 512-byte rows, 16-byte piece c of row r
+        // at c ^ (r & 31); in by LDS DMA, arithmetic in place, fp32 rows and their 16-bit copies out whole.
+        unsigned char* const img = smem + (size_t)wvu * 32 * 512;            // this wave's 32 image rows
+        const size_t rpitch = (size_t)C_pad * 4;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int trow0 = 64 * wv + 32 * p;                              // first tile row of this wave's pass
+            float* const gbase = resid + (size_t)(Gd + m0 + trow0) * C_pad + nb * 128;
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (int)(32 * rpitch), 0x00020000);
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {                                   // DMA q: image rows 2q, 2q + 1
+                const int r = 2 * q + (lane >> 5);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(img + q * 1024), 16,
+                                                         (unsigned)(r * rpitch) + (unsigned)(((lane & 31) ^ r) << 4), 0, 0, 0);
+            }
+            AZ_DMA_LANDED();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned rmask = t4_real_mask(m0 + 64 * wvu + 32 * p, M, P, W, N);     // wave-uniform: which of the 32 rows are board cells
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 bv = *(const float4*)(bias + nb * 128 + 64 * q + 4 * lrc);  // channels 64 q + 4 lrc .. + 3
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * bb + 4 * gc + r;                            // image row = position inside the wave's 32
+                            const bool real = rmask >> row & 1u;
+                            const float cap = real ? Prec<PR>::cap() : 0.f;
+                            float4* const slot = (float4*)(img + row * 512 + (((16 * q + lrc) ^ row) << 4));
+                            const float4 rv = *slot;
+                            float v0 = acc[4 * q][2 * p + bb][r] + bv.x, v1 = acc[4 * q + 1][2 * p + bb][r] + bv.y;
+                            float v2 = acc[4 * q + 2][2 * p + bb][r] + bv.z, v3 = acc[4 * q + 3][2 * p + bb][r] + bv.w;
+                            v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+                            if (relu) { v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap); }
+                            else if (!real) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+                            *slot = make_float4(v0, v1, v2, v3);
+                        }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // this wave's LDS writes are done (lgkmcnt 0)
+            __builtin_amdgcn_sched_barrier(0);
+            // fp32 rows back to the residual stream: 2 rows per trip
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int r = 2 * it + (lane >> 5), ph = lane & 31;
+                const float4 v = *(const float4*)(img + r * 512 + (ph << 4));
+                *(float4*)(gbase + (size_t)r * C_pad + ((ph ^ r) << 2)) = v;
+            }
+            // and their 16-bit copies, the next convolution's input: 4 rows per trip, 8 channels per lane
+            unsigned short* const obase = out + (size_t)(Gd + m0 + trow0) * C_pad + nb * 128;
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int r = 4 * it + (lane >> 4), c = lane & 15;
+                const float4 a = *(const float4*)(img + r * 512 + (((2 * c) ^ r) << 4));
+                const float4 bq = *(const float4*)(img + r * 512 + (((2 * c + 1) ^ r) << 4));
+                uint4 o;
+                if (relu) {                                                  // already in [0, cap]
+                    o.x = Prec<PR>::pack2(a.x, a.y); o.y = Prec<PR>::pack2(a.z, a.w);
+                    o.z = Prec<PR>::pack2(bq.x, bq.y); o.w = Prec<PR>::pack2(bq.z, bq.w);
+                } else {
+                    o.x = (unsigned)Prec<PR>::to16(a.x) | ((unsigned)Prec<PR>::to16(a.y) << 16);
+                    o.y = (unsigned)Prec<PR>::to16(a.z) | ((unsigned)Prec<PR>::to16(a.w) << 16);
+                    o.z = (unsigned)Prec<PR>::to16(bq.x) | ((unsigned)Prec<PR>::to16(bq.y) << 16);
+                    o.w = (unsigned)Prec<PR>::to16(bq.z) | ((unsigned)Prec<PR>::to16(bq.w) << 16);
+                }
+                *(uint4*)(obase + (size_t)r * C_pad + c * 8) = o;
+            }
+            __syncthreads();                                                 // reads of this pass are done before the next pass's DMA lands
+        }
+        return;
+    }
+    // first convolution of a ResBlock: 256 rows x 128 channels of 16-bit output, 256-byte rows, piece c of row r at c ^ (r & 15)
+    unsigned char* const sO = smem;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const unsigned rmask = t4_real_mask(m0 + 64 * wvu + 32 * p, M, P, W, N);             // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 bv = *(const float4*)(bias + nb * 128 + 64 * q + 4 * lrc);          // channels 64 q + 4 lrc .. + 3
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 64 * wv + 32 * p + 16 * bb + 4 * gc + r;                  // tile row of this position
+                    const bool real = rmask >> (16 * bb + 4 * gc + r) & 1u;
+                    const unsigned keep = real ? 0xFFFFFFFFu : 0u;
+                    const float cap = real ? Prec<PR>::cap() : 0.f;
+                    const float v0 = acc[4 * q][2 * p + bb][r] + bv.x, v1 = acc[4 * q + 1][2 * p + bb][r] + bv.y;
+                    const float v2 = acc[4 * q + 2][2 * p + bb][r] + bv.z, v3 = acc[4 * q + 3][2 * p + bb][r] + bv.w;
+                    uint2* const slot = (uint2*)(sO + rr * 256 + (((8 * q + (lrc >> 1)) ^ (rr & 15)) << 4) + 8 * (lrc & 1));
+                    uint2 o;
+                    if (relu) {                              // ReLU + saturation + padding mask: one v_med3 per value
+                        o.x = Prec<PR>::pack2(relu_cap(v0, cap), relu_cap(v1, cap));
+                        o.y = Prec<PR>::pack2(relu_cap(v2, cap), relu_cap(v3, cap));
+                    } else {
+                        o.x = ((unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16)) & keep;
+                        o.y = ((unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16)) & keep;
+                    }
+                    *slot = o;
+                }
+        }
     }
     __syncthreads();
 #pragma unroll 4
@@ -1322,6 +1617,7 @@ extern "C" int az_tower_configure(void) {
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
+    SETA(az_conv3x3_t256s_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256s_kernel<1>, 80 * 1024);
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
     SETA(az_heads_kernel<0>, 128 * 1024); SETA(az_heads_kernel<1>, 128 * 1024);
     SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
@@ -1348,21 +1644,29 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
     BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, w, bias, N, C_pad, Gd, c_in);
 }
 
-extern "C" void az_launch_conv3x3(hipStream_t s, int prec, const unsigned short* in, unsigned short* out,
+// Which per-layer convolution kernel a tower uses; read once when the tower is created, because the order of the
+// weight image's rows goes with it.  0: 256 rows on 16x16x32 MFMAs, activations as A (rows in the order of
+// AzFoldArgs::layer16); 1: 256 rows on 32x32x16, weights as A (AZ_T256_32); 2: 128 rows (AZ_CONV_T128).
+extern "C" int az_conv_kind(void) {
+    if (getenv("AZ_CONV_T128")) return 2;
+    if (getenv("AZ_T256_32")) return 1;
+    return 0;
+}
+
+extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
                                   float* resid, const unsigned short* wpk, const float* bias,
                                   int C_pad, int M, int N, int Gd, int relu) {
-    if (!getenv("AZ_CONV_T128")) {                                        // 256 rows x 128 channels, two workgroups per CU
+    if (kind != 2) {                                                      // 256 rows x 128 channels, two workgroups per CU
         const int tiles = (M + T4_M - 1) / T4_M;
         size_t sm = 2 * (size_t)W2_BYTES + (size_t)t4_slab_rows(Gd) * 128;
         if (sm < (size_t)T4_M * 256) sm = (size_t)T4_M * 256;               // the epilogue image
-        if (getenv("AZ_T256_PLAIN_ORDER")) {
-            BY_PREC(az_conv3x3_t256_kernel, dim3(tiles, C_pad / 128), dim3(256), sm, s,
-                    in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, 0);
-            return;
-        }
-        const int xcd_tiles = (tiles + 7) / 8;
-        BY_PREC(az_conv3x3_t256_kernel, dim3(8 * xcd_tiles * (C_pad / 128)), dim3(256), sm, s,
-                in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, xcd_tiles);
+        const bool plain = getenv("AZ_T256_PLAIN_ORDER") != nullptr;
+        const int xcd_tiles = plain ? 0 : (tiles + 7) / 8;
+        const dim3 grid = plain ? dim3(tiles, C_pad / 128) : dim3(8 * xcd_tiles * (C_pad / 128));
+        if (kind == 0)
+            BY_PREC(az_conv3x3_t256s_kernel, grid, dim3(256), sm, s, in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, xcd_tiles);
+        else
+            BY_PREC(az_conv3x3_t256_kernel, grid, dim3(256), sm, s, in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, xcd_tiles);
         return;
     }
     const int tiles = (M + T2_M - 1) / T2_M;

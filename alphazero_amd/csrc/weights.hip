@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(256) az_fold_conv_kernel(AzFoldArgs a) {
             a.conv_wf[(((size_t)L * 9 + tap) * 128 + fused_row(co)) * 128 + ci] = v;
         else {                                                // [layer][nb][sc][tap][n][k]
             const size_t chunk = ((size_t)(co / 128) * nblk + ci / 128) * 9 + tap;
-            a.conv_w[(size_t)L * a.conv_layer_elems + chunk * (128 * 128) + (size_t)(co % 128) * 128 + ci % 128] = v;
+            const int row = a.layer16 ? fused_row(co % 128) : co % 128;
+            a.conv_w[(size_t)L * a.conv_layer_elems + chunk * (128 * 128) + (size_t)row * 128 + ci % 128] = v;
         }
     }
 }

@@ -131,16 +131,18 @@ def test_per_layer_path_matches_fused_path(monkeypatch):
     assert np.abs(p1 - p2).max() < TOL and np.abs(v1 - v2).max() < TOL
 
 
-@pytest.mark.parametrize("kernel", ["t256", "t128"])
+@pytest.mark.parametrize("kernel", ["t256", "t256_32", "t128"])
 @pytest.mark.parametrize("N,B", [(9, 6), (15, 5), (19, 3)])
 def test_wide_tower_256_channels_matches_torch(monkeypatch, kernel, N, B):
     """BASELINE config 5 shape class: 256-channel blocks (per-layer path), on the 256-row kernel
-    (the default) and on the 128-row kernel; batches whose last tile is partial and whose tiles
-    straddle boards."""
+    (the default: 16x16x32 MFMAs, activations as the A operand), on its 32x32x16 form with the weights
+    as A, and on the 128-row kernel; batches whose last tile is partial and whose tiles straddle boards."""
     import torch
     torch.set_num_threads(8)
     if kernel == "t128":
         monkeypatch.setenv("AZ_CONV_T128", "1")
+    if kernel == "t256_32":
+        monkeypatch.setenv("AZ_T256_32", "1")
     Cs = [256, 256, 256]
     blob = synth.make_blob(N, 3, Cs, 31)
     boards = synth.random_boards(B, N, seed=31)
