@@ -666,6 +666,7 @@ az_conv3x3_t256_kernel(const unsigned short* __restrict__ in, unsigned short* __
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 template <int PR>
 __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& b);
 // Which of the 32 consecutive raster rows from m are cells of a board (bit k: row m + k): one walk over the
@@ -684,8 +685,10 @@ __device__ __forceinline__ unsigned t4_real_mask(int m, int M, int P, int W, int
 // The 256-row kernel above on v_mfma_f32_16x16x32 with the activations as the A operand: the chip holds a higher
 // clock on this shape and with the zeros (ReLU outputs, padding) in A (tools/microbench/mfma_operand_power.hip).
 // Same tiles, LDS images, weight stream and slab handling; what changes is the k-step (two of 32 per chunk, 32 MFMAs
-// on 4 activation + 8 weight fragments), the accumulator layout and with it the two epilogues, and the order of the
-// weight image's rows (AzFoldArgs::layer16: row 16 a + l of a 128-channel block holds channel 64 (a >> 2) + 4 l + (a & 3)).
+// on 4 activation + 8 weight fragments), the accumulator layout, and the order of the weight image's rows
+// (AzFoldArgs::layer16: row 16 a + l of a 128-channel block holds channel 64 (a >> 2) + 4 l + (a & 3)).  In that
+// layout a lane holds four consecutive channels of a position and a 16-lane MFMA row 64 of them, so the outputs go
+// from the accumulators to HBM in whole cache lines; LDS is used in the epilogue only to bring the residual in.
 template <int PR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
@@ -724,10 +727,6 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
 
     // acc[a][b][r]: position 64 wv + 16 b + 4 gc + r, channel 64 (a >> 2) + 4 lrc + (a & 3) of the block
     f32x4 acc[8][4];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // weights: chunk t = kc*9 + tap lives in the packed image at ((nb*n_sc + kc/2)*9 + tap) * 32 KB, columns
     // [64*(kc&1), +64) of every 256-byte row; piece q = it*256 + tid of a chunk: LDS row it*32 + (tid >> 3),
@@ -757,6 +756,24 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
 #pragma unroll
     for (int it = 0; it < 4; ++it) STAGE_W4(1, it);          // total >= 18: chunk 1 always exists
     STAGE_A4(0);
+    // The accumulators start from the bias.  Buffer addressing for the epilogue: scalar resource over the tile's 256
+    // rows of this channel block, the lane's first value as a 32-bit offset, (row, channel half) as a scalar offset
+    // -- no address registers per access.
+    const size_t tile0 = (size_t)(Gd + m0) * C_pad + nb * 128;
+    const unsigned lane0 = (unsigned)((64 * wv + 4 * gc) * C_pad + 4 * lrc);                 // in elements
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((resid ? resid : (float*)nullptr) + (resid ? tile0 : 0)), 0, resid ? T4_M * C_pad * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + tile0), 0, T4_M * C_pad * 2, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float4 bv = *(const float4*)(bias + nb * 128 + 64 * q + 4 * lrc);              // channels 64 q + 4 lrc .. + 3
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[4 * q][b][r] = bv.x; acc[4 * q + 1][b][r] = bv.y; acc[4 * q + 2][b][r] = bv.z; acc[4 * q + 3][b][r] = bv.w;
+            }
+    }
     AZ_DMA_LANDED();
     __syncthreads();
 
@@ -839,122 +856,76 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) asm volatile("" : "+a"(acc[a][b]));
-    __syncthreads();                                         // all waves done with the buffers: LDS becomes the output image
-
+    // Epilogue.  A lane holds four consecutive channels of a position and a 16-lane MFMA row 64 of them, so results
+    // go from the accumulators to HBM in whole cache lines: one store instruction = four rows x 64 channels, 256
+    // contiguous bytes per row of the fp32 residual stream, 128 of the 16-bit image the next convolution reads.  One
+    // value = one v_med3 (ReLU + 16-bit saturation + padding-row mask through a cap of 0) and half a packed convert.
+    //
+    // Second convolution of a ResBlock: x = relu(conv + bias + x) with the residual stream x in fp32 (network.hpp:36
+    // in the reference's own precision; only the copy that feeds the next convolution is rounded to 16 bits).  The
+    // stream comes in through LDS, by DMA, in two passes of 128 tile rows: a wave's own 32 rows per pass (tile rows
+    // 64 wv + 32 p + [0, 32)) as a plain fp32 [32][128] image -- in the accumulator layout a 16-lane group reads 16
+    // distinct 16-byte slots whatever the row, no swizzle.  Pass 1 is requested as soon as pass 0 sits in registers
+    // and lands under pass 0's arithmetic and stores.  (Straight into registers instead, in the prologue or here,
+    // the same loads cost 225 us more per launch at batch 8 192: 32 per lane in flight at once, all exposed.)
+    unsigned char* const img = smem + (size_t)wvu * 32 * 512;                // this wave's 32 image rows
+    const unsigned dma_voff = (unsigned)((lane >> 5) * C_pad * 4 + (lane & 31) * 16);
+#define RES_DMA(p_) do { _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_)      /* DMA q: image rows 2q, 2q + 1 */ \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(img + q_ * 1024), 16, dma_voff, \
+                                                 (64 * wvu + 32 * (p_) + 2 * q_) * C_pad * 4, 0, 0); } while (0)
     if (resid) {
-        // Second convolution of a ResBlock: x = relu(conv + bias + residual) with the residual stream in fp32
-        // (network.hpp:36 in the reference's own precision; only the copy that feeds the next convolution is
-        // rounded to 16 bits).  Two passes of 128 tile rows; a wave handles its own 32 rows per pass end to end
-        // (rows 64 wv + 32 p + [0, 32) of the tile = rows 32 wv + [0, 32) of the LDS image), so the passes need
-        // no hand-over between waves.  Image: fp32 [128 rows][128 ch], 512-byte rows, 16-byte piece c of row r
-        // at c ^ (r & 31); in by LDS DMA, arithmetic in place, fp32 rows and their 16-bit copies out whole.
-        unsigned char* const img = smem + (size_t)wvu * 32 * 512;            // this wave's 32 image rows
-        const size_t rpitch = (size_t)C_pad * 4;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int trow0 = 64 * wv + 32 * p;                              // first tile row of this wave's pass
-            float* const gbase = resid + (size_t)(Gd + m0 + trow0) * C_pad + nb * 128;
-            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (int)(32 * rpitch), 0x00020000);
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {                                   // DMA q: image rows 2q, 2q + 1
-                const int r = 2 * q + (lane >> 5);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(img + q * 1024), 16,
-                                                         (unsigned)(r * rpitch) + (unsigned)(((lane & 31) ^ r) << 4), 0, 0, 0);
-            }
-            AZ_DMA_LANDED();
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const unsigned rmask = t4_real_mask(m0 + 64 * wvu + 32 * p, M, P, W, N);     // wave-uniform: which of the 32 rows are board cells
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float4 bv = *(const float4*)(bias + nb * 128 + 64 * q + 4 * lrc);  // channels 64 q + 4 lrc .. + 3
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * bb + 4 * gc + r;                            // image row = position inside the wave's 32
-                            const bool real = rmask >> row & 1u;
-                            const float cap = real ? Prec<PR>::cap() : 0.f;
-                            float4* const slot = (float4*)(img + row * 512 + (((16 * q + lrc) ^ row) << 4));
-                            const float4 rv = *slot;
-                            float v0 = acc[4 * q][2 * p + bb][r] + bv.x, v1 = acc[4 * q + 1][2 * p + bb][r] + bv.y;
-                            float v2 = acc[4 * q + 2][2 * p + bb][r] + bv.z, v3 = acc[4 * q + 3][2 * p + bb][r] + bv.w;
-                            v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-                            if (relu) { v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap); }
-                            else if (!real) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
-                            *slot = make_float4(v0, v1, v2, v3);
-                        }
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);                              // this wave's LDS writes are done (lgkmcnt 0)
-            __builtin_amdgcn_sched_barrier(0);
-            // fp32 rows back to the residual stream: 2 rows per trip
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int r = 2 * it + (lane >> 5), ph = lane & 31;
-                const float4 v = *(const float4*)(img + r * 512 + (ph << 4));
-                *(float4*)(gbase + (size_t)r * C_pad + ((ph ^ r) << 2)) = v;
-            }
-            // and their 16-bit copies, the next convolution's input: 4 rows per trip, 8 channels per lane
-            unsigned short* const obase = out + (size_t)(Gd + m0 + trow0) * C_pad + nb * 128;
-#pragma unroll 4
-            for (int it = 0; it < 8; ++it) {
-                const int r = 4 * it + (lane >> 4), c = lane & 15;
-                const float4 a = *(const float4*)(img + r * 512 + (((2 * c) ^ r) << 4));
-                const float4 bq = *(const float4*)(img + r * 512 + (((2 * c + 1) ^ r) << 4));
-                uint4 o;
-                if (relu) {                                                  // already in [0, cap]
-                    o.x = Prec<PR>::pack2(a.x, a.y); o.y = Prec<PR>::pack2(a.z, a.w);
-                    o.z = Prec<PR>::pack2(bq.x, bq.y); o.w = Prec<PR>::pack2(bq.z, bq.w);
-                } else {
-                    o.x = (unsigned)Prec<PR>::to16(a.x) | ((unsigned)Prec<PR>::to16(a.y) << 16);
-                    o.y = (unsigned)Prec<PR>::to16(a.z) | ((unsigned)Prec<PR>::to16(a.w) << 16);
-                    o.z = (unsigned)Prec<PR>::to16(bq.x) | ((unsigned)Prec<PR>::to16(bq.y) << 16);
-                    o.w = (unsigned)Prec<PR>::to16(bq.z) | ((unsigned)Prec<PR>::to16(bq.w) << 16);
-                }
-                *(uint4*)(obase + (size_t)r * C_pad + c * 8) = o;
-            }
-            __syncthreads();                                                 // reads of this pass are done before the next pass's DMA lands
-        }
-        return;
+        __syncthreads();                                                     // all waves done with the buffers
+        RES_DMA(0);
     }
-    // first convolution of a ResBlock: 256 rows x 128 channels of 16-bit output, 256-byte rows, piece c of row r at c ^ (r & 15)
-    unsigned char* const sO = smem;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const unsigned rmask = t4_real_mask(m0 + 64 * wvu + 32 * p, M, P, W, N);             // wave-uniform
+        float4 rv[2][2][4];
+        if (resid) {
+            AZ_DMA_LANDED();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float4 bv = *(const float4*)(bias + nb * 128 + 64 * q + 4 * lrc);          // channels 64 q + 4 lrc .. + 3
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
+                for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = 64 * wv + 32 * p + 16 * bb + 4 * gc + r;                  // tile row of this position
-                    const bool real = rmask >> (16 * bb + 4 * gc + r) & 1u;
-                    const unsigned keep = real ? 0xFFFFFFFFu : 0u;
-                    const float cap = real ? Prec<PR>::cap() : 0.f;
-                    const float v0 = acc[4 * q][2 * p + bb][r] + bv.x, v1 = acc[4 * q + 1][2 * p + bb][r] + bv.y;
-                    const float v2 = acc[4 * q + 2][2 * p + bb][r] + bv.z, v3 = acc[4 * q + 3][2 * p + bb][r] + bv.w;
-                    uint2* const slot = (uint2*)(sO + rr * 256 + (((8 * q + (lrc >> 1)) ^ (rr & 15)) << 4) + 8 * (lrc & 1));
-                    uint2 o;
-                    if (relu) {                              // ReLU + saturation + padding mask: one v_med3 per value
-                        o.x = Prec<PR>::pack2(relu_cap(v0, cap), relu_cap(v1, cap));
-                        o.y = Prec<PR>::pack2(relu_cap(v2, cap), relu_cap(v3, cap));
-                    } else {
-                        o.x = ((unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16)) & keep;
-                        o.y = ((unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16)) & keep;
-                    }
-                    *slot = o;
-                }
+                    for (int r = 0; r < 4; ++r)
+                        rv[q][bb][r] = *(const float4*)(img + (16 * bb + 4 * gc + r) * 512 + ((16 * q + lrc) << 4));
+            if (p == 0) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);                          // the image is in registers (lgkmcnt 0)
+                __builtin_amdgcn_sched_barrier(0);
+                RES_DMA(1);
+            }
         }
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = 2 * p + bb;
+                const bool real = rmask >> (16 * bb + 4 * gc + r) & 1u;
+                const float cap = real ? Prec<PR>::cap() : 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int so = (16 * b + r) * C_pad + 64 * q;                            // scalar: row and channel half
+                    float v0 = acc[4 * q][b][r], v1 = acc[4 * q + 1][b][r], v2 = acc[4 * q + 2][b][r], v3 = acc[4 * q + 3][b][r];
+                    if (resid) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
+                    uint2 o;
+                    if (relu) {
+                        v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap);
+                        o.x = Prec<PR>::pack2(v0, v1); o.y = Prec<PR>::pack2(v2, v3);        // already in [0, cap]
+                    } else {
+                        if (!real) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+                        o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
+                        o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
+                    }
+                    if (resid)
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)},
+                                                               rrs, lane0 * 4, so * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, ors, lane0 * 2, so * 2, 0);
+                }
+            }
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int i = tid; i < T4_M * 16; i += 256) {
-        const int r = i >> 4, c = i & 15;
-        *(uint4*)(out + (size_t)(Gd + m0 + r) * C_pad + nb * 128 + c * 8) = *(const uint4*)(sO + r * 256 + ((c ^ (r & 15)) << 4));
-    }
+#undef RES_DMA
 }
 
 // ------------------------------------------------------------ fused tower
