@@ -669,19 +669,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 template <int PR>
 __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& b);
-// Which of the 32 consecutive raster rows from m are cells of a board (bit k: row m + k): one walk over the
-// raster with wave-uniform arguments, so it runs on the scalar unit.
-__device__ __forceinline__ unsigned t4_real_mask(int m, int M, int P, int W, int N) {
-    const int pp = m % P;
-    int y = pp / W, x = pp - y * W;
-    unsigned mask = 0u;
-    for (int k = 0; k < 32; ++k) {
-        if (m + k < M && y < N && x < N) mask |= 1u << k;
-        if (++x == W) { x = 0; if (++y == W) y = 0; }
-    }
-    return mask;
-}
-
 // The 256-row kernel above on v_mfma_f32_16x16x32 with the activations as the A operand: the chip holds a higher
 // clock on this shape and with the zeros (ReLU outputs, padding) in A (tools/microbench/mfma_operand_power.hip).
 // Same tiles, LDS images, weight stream and slab handling; what changes is the k-step (two of 32 per chunk, 32 MFMAs
@@ -773,6 +760,18 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
             for (int r = 0; r < 4; ++r) {
                 acc[4 * q][b][r] = bv.x; acc[4 * q + 1][b][r] = bv.y; acc[4 * q + 2][b][r] = bv.z; acc[4 * q + 3][b][r] = bv.w;
             }
+    }
+    // Which of the wave's 64 rows are cells of a board (the others are the zero column and row of the padded raster
+    // and the rows past the last board): lane l works it out for row 64 wv + l, the ballot keeps it in two scalars.
+    // floor((v + 0.5) / d) through the reciprocal is exact here: v < 1024, d <= 512.
+    unsigned long long realmask;
+    {
+        const int pp0 = m0 % P;                              // scalar
+        int pp = pp0 + 64 * wv + lane;
+        pp -= (int)(((float)pp + 0.5f) * (1.0f / (float)P)) * P;
+        const int y = (int)(((float)pp + 0.5f) * (1.0f / (float)W));
+        const int x = pp - y * W;
+        realmask = __ballot(m0 + 64 * wv + lane < M && y < N && x < N);
     }
     AZ_DMA_LANDED();
     __syncthreads();
@@ -879,7 +878,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const unsigned rmask = t4_real_mask(m0 + 64 * wvu + 32 * p, M, P, W, N);             // wave-uniform
+        const unsigned rmask = (unsigned)(realmask >> (32 * p));                             // rows 32 p .. 32 p + 31 of the wave
         float4 rv[2][2][4];
         if (resid) {
             AZ_DMA_LANDED();
