@@ -725,6 +725,8 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
 #define CHUNK_SRC4(t_) ((((t_) / 9 >> 1) * 9 + (t_) % 9) * (128 * 128 * 2) + (((t_) / 9) & 1) * 128)
 #define STAGE_W4(t_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
         wrsrc, (lds_void*)(w_dst + ((t_) & 1) * W2_BYTES + (it_) * 4096), 16, w_voff, CHUNK_SRC4(t_) + (it_) * 8192, 0, 0)
+#define STAGE_W4S(buf_, src_, it_) __builtin_amdgcn_raw_ptr_buffer_load_lds( \
+        wrsrc, (lds_void*)(w_dst + (buf_) * W2_BYTES + (it_) * 4096), 16, w_voff, (src_) + (it_) * 8192, 0, 0)
     // slab: DMA q covers rows 8q .. 8q+7 (lane: row 8q + (lane >> 3), physical piece lane & 7); wave w issues
     // q = w, w+4, ..., so (row >> 1) & 7 = 4 (w & 1) + (lane >> 4) is a per-lane constant
     const size_t a_left = (size_t)(rows_total - m0) * C_pad * 2;
@@ -780,8 +782,13 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
     // Slab and weight images have 128-byte rows (64 k = 8 pieces, piece c of row r at c ^ ((r >> 1) & 7)); the two
     // k slices that share a ds_read_b128 lane group read pieces 4 apart and rows that are complementary sets closed
     // under + 8, so every group covers 16 distinct slots.  A chunk is two k-steps of 32.  The four activation
-    // fragments are double-buffered; a weight fragment is refilled in place right behind its tile's last MFMA
-    // (tile-major order: its next use is 28 MFMAs away), which keeps the kernel inside 256 registers.
+    // fragments are double-buffered; a weight fragment is refilled in place behind its tile's last MFMA (tile-major
+    // order: its next use is at least 21 MFMAs away), which keeps the kernel inside 256 registers.
+    // A wave must keep the MFMA pipe fed on its own while its neighbour on the SIMD is in a memory phase, so the
+    // loop has no branches and no wait it could avoid: the hand-over barrier sits behind MFMA 7 of the second
+    // k-step, when the reads of the first have long completed (a barrier waits for all of a wave's LDS reads), and
+    // the second k-step's own reads follow it; the weight DMA of chunk t + 2 is issued unconditionally, past the
+    // end as the last chunk once more, into a buffer that is dead by then.
     const int s_base = Gd + 64 * wv + lrc;                   // slab row of this lane's position in block 0
     const int swzW = (lrc >> 1) & 7;
     const unsigned char* const wrow = sW + lrc * 128;
@@ -812,26 +819,36 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
         const unsigned char* nX = sA + ns0 * 128;
         const unsigned char* bW = wrow + (t & 1) * W2_BYTES;
         const unsigned char* nW = wrow + ((t + 1) & 1) * W2_BYTES;
+        const int t2 = t + 2 < total ? t + 2 : total - 1;
+        const int w_src = CHUNK_SRC4(t2);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks, n = ks ^ 1;
             const unsigned char* rX = ks == 0 ? bX + (((kpc + 2) ^ sz) << 4) : nX + ((kpc ^ nsz) << 4);
             const unsigned char* rW = ks == 0 ? bW + (((kpc + 2) ^ swzW) << 4) : nW + ((kpc ^ swzW) << 4);
-            if (ks == 1) {
-                // hand-over: every wave holds its last fragments of this chunk, the next chunk has landed
-                AZ_DMA_LANDED();
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int m = 4 * a + b;
                     mfma16<PR>(acc[a][b], fx[c][b], fw[a]);
-                    if (b == 3) fw[a] = *(const u32x4*)(rW + a * 2048);
-                    if (m == 0 || m == 1 || m == 2 || m == 5) fx[n][m < 3 ? m : 3] = *(const u32x4*)(rX + (m < 3 ? m : 3) * 2048);
-                    if (ks == 1 && t + 2 < total && m >= 16 && (m & 3) == 0) STAGE_W4(t + 2, (m - 16) >> 2);
+                    if (ks == 0) {
+                        if (b == 3) fw[a] = *(const u32x4*)(rW + a * 2048);
+                        if (m == 0 || m == 1 || m == 2 || m == 5) fx[n][m < 3 ? m : 3] = *(const u32x4*)(rX + (m < 3 ? m : 3) * 2048);
+                    } else {
+                        if (m == 7) {
+                            // hand-over: every wave has its last fragments of this chunk, the next chunk has landed
+                            AZ_DMA_LANDED();
+                            __syncthreads();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (m == 8 || m == 9 || m == 10 || m == 12) fx[n][m < 11 ? m - 8 : 3] = *(const u32x4*)(rX + (m < 11 ? m - 8 : 3) * 2048);
+                        if (m == 11) fw[0] = *(const u32x4*)(rW);
+                        if (m == 13) fw[1] = *(const u32x4*)(rW + 2048);
+                        if (m == 14) fw[2] = *(const u32x4*)(rW + 2 * 2048);
+                        if (m >= 15 && b == 3) fw[a] = *(const u32x4*)(rW + a * 2048);
+                        if (m >= 16 && (m & 3) == 0) STAGE_W4S(t & 1, w_src, (m - 16) >> 2);
+                    }
                 }
         }
         if (tap == 8 && t + 1 < total) {
@@ -845,9 +862,12 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
             const unsigned char* rX = nX + ((kpc ^ nsz) << 4);
 #pragma unroll
             for (int b = 0; b < 4; ++b) fx[0][b] = *(const u32x4*)(rX + b * 2048);
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // nothing pending where this path rejoins the loop
         }
     }
+    AZ_DMA_LANDED();                                         // the weight pieces requested past the end
 #undef STAGE_W4
+#undef STAGE_W4S
 #undef STAGE_A4
 #undef CHUNK_SRC4
     asm volatile("s_nop 15\n\ts_nop 7");                     // last MFMAs -> first read of their results
