@@ -676,11 +676,14 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& 
 // (AzFoldArgs::layer16: row 16 a + l of a 128-channel block holds channel 64 (a >> 2) + 4 l + (a & 3)).  In that
 // layout a lane holds four consecutive channels of a position and a 16-lane MFMA row 64 of them, so the outputs go
 // from the accumulators to HBM in whole cache lines; LDS is used in the epilogue only to bring the residual in.
-template <int PR>
+// RESID: second convolution of a ResBlock (resid = the fp32 residual stream, updated in place); RELU: network.hpp:33,36.
+// Both are template parameters so that the epilogue is straight-line code (as run-time flags they cost three
+// branches and both conversions per four values).
+template <int PR, bool RESID, bool RELU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
-                       float* resid /* fp32 residual stream, updated in place; null: none */, const unsigned short* __restrict__ wpk,
-                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int relu, int xcd_tiles) {
+                       float* resid /* RESID: the fp32 residual stream, else unused */, const unsigned short* __restrict__ wpk,
+                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int xcd_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = N + 1, P = W * W;
     const int rows_total = n_tiles * T4_M + 2 * Gd;          // rows of the activation buffers
@@ -751,7 +754,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
     const size_t tile0 = (size_t)(Gd + m0) * C_pad + nb * 128;
     const unsigned lane0 = (unsigned)((64 * wv + 4 * gc) * C_pad + 4 * lrc);                 // in elements
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((resid ? resid : (float*)nullptr) + (resid ? tile0 : 0)), 0, resid ? T4_M * C_pad * 4 : 0, 0x00020000);
+        (void*)(RESID ? resid + tile0 : (float*)nullptr), 0, RESID ? T4_M * C_pad * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + tile0), 0, T4_M * C_pad * 2, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -892,7 +895,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
 #define RES_DMA(p_) do { _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_)      /* DMA q: image rows 2q, 2q + 1 */ \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(img + q_ * 1024), 16, dma_voff, \
                                                  (64 * wvu + 32 * (p_) + 2 * q_) * C_pad * 4, 0, 0); } while (0)
-    if (resid) {
+    if constexpr (RESID) {
         __syncthreads();                                                     // all waves done with the buffers
         RES_DMA(0);
     }
@@ -900,7 +903,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
     for (int p = 0; p < 2; ++p) {
         const unsigned rmask = (unsigned)(realmask >> (32 * p));                             // rows 32 p .. 32 p + 31 of the wave
         float4 rv[2][2][4];
-        if (resid) {
+        if constexpr (RESID) {
             AZ_DMA_LANDED();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -927,9 +930,9 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
                 for (int q = 0; q < 2; ++q) {
                     const int so = (16 * b + r) * C_pad + 64 * q;                            // scalar: row and channel half
                     float v0 = acc[4 * q][b][r], v1 = acc[4 * q + 1][b][r], v2 = acc[4 * q + 2][b][r], v3 = acc[4 * q + 3][b][r];
-                    if (resid) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
+                    if constexpr (RESID) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
                     uint2 o;
-                    if (relu) {
+                    if constexpr (RELU) {
                         v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap);
                         o.x = Prec<PR>::pack2(v0, v1); o.y = Prec<PR>::pack2(v2, v3);        // already in [0, cap]
                     } else {
@@ -937,7 +940,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
                         o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
                         o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                     }
-                    if (resid)
+                    if constexpr (RESID)
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)},
                                                                rrs, lane0 * 4, so * 4, 0);
                     __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, ors, lane0 * 2, so * 2, 0);
@@ -1607,7 +1610,10 @@ extern "C" int az_tower_configure(void) {
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
-    SETA(az_conv3x3_t256s_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256s_kernel<1>, 80 * 1024);
+#define SETA4(pr) SETA((az_conv3x3_t256s_kernel<pr, false, false>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, false, true>), 80 * 1024); \
+                 SETA((az_conv3x3_t256s_kernel<pr, true, false>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, true, true>), 80 * 1024)
+    SETA4(0); SETA4(1);
+#undef SETA4
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
     SETA(az_heads_kernel<0>, 128 * 1024); SETA(az_heads_kernel<1>, 128 * 1024);
     SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
@@ -1653,8 +1659,15 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsig
         const bool plain = getenv("AZ_T256_PLAIN_ORDER") != nullptr;
         const int xcd_tiles = plain ? 0 : (tiles + 7) / 8;
         const dim3 grid = plain ? dim3(tiles, C_pad / 128) : dim3(8 * xcd_tiles * (C_pad / 128));
-        if (kind == 0)
-            BY_PREC(az_conv3x3_t256s_kernel, grid, dim3(256), sm, s, in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, xcd_tiles);
+        if (kind == 0) {
+#define T4S_GO(pr, rs, rl) hipLaunchKernelGGL((az_conv3x3_t256s_kernel<pr, rs, rl>), grid, dim3(256), sm, s, \
+                                              in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, xcd_tiles)
+#define T4S_BY_FLAGS(pr) do { if (resid) { if (relu) T4S_GO(pr, true, true); else T4S_GO(pr, true, false); } \
+                              else { if (relu) T4S_GO(pr, false, true); else T4S_GO(pr, false, false); } } while (0)
+            if (prec == 1) T4S_BY_FLAGS(1); else T4S_BY_FLAGS(0);
+#undef T4S_BY_FLAGS
+#undef T4S_GO
+        }
         else
             BY_PREC(az_conv3x3_t256_kernel, grid, dim3(256), sm, s, in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, relu, xcd_tiles);
         return;
