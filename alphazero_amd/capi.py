@@ -14,13 +14,13 @@ LIB_PATH = os.environ.get("AZ_HIP_LIB") or os.path.join(_HERE, "libazhip.so")   
 
 AZ_EVAL_TOWER, AZ_EVAL_HASH, AZ_EVAL_EXTERNAL = 0, 1, 2
 AZ_NOISE_EXPLICIT, AZ_NOISE_DEVICE = 0, 1
-AZ_PREC_FP16, AZ_PREC_BF16 = 0, 1          # fp16 operands are the default (1e-3 parity mode)
+AZ_PREC_FP16, AZ_PREC_BF16, AZ_PREC_FP16X3 = 0, 1, 2   # fp16 operands are the default; FP16X3 = compensated three-pass parity mode
 AZ_MAX_LAYERS = 64
 AZ_OK, AZ_E_ARG, AZ_E_HIP, AZ_E_CAPACITY, AZ_E_STATE, AZ_E_NOWEIGHTS = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [
     "az_last_error", "az_ctx_create", "az_ctx_destroy", "az_sync", "az_stream", "az_weights_size",
-    "az_load_weights", "az_load_weights_dev", "az_env_reset", "az_env_step", "az_env_boards",
+    "az_load_weights", "az_load_weights_dev", "az_weights_info_get", "az_env_reset", "az_env_step", "az_env_boards",
     "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
     "az_tower_forward_static", "az_tower_static_max_batch",
     "az_group_create", "az_group_destroy", "az_group_contexts", "az_group_context", "az_group_load_weights",
@@ -49,7 +49,14 @@ class AzConfig(C.Structure):
         ("Cs", C.c_int * AZ_MAX_LAYERS), ("vl", C.c_float), ("c_puct", C.c_float), ("node_cap", C.c_int),
         ("max_budget", C.c_int), ("eval_mode", C.c_int), ("noise_mode", C.c_int), ("precision", C.c_int),
         ("seed", C.c_uint64), ("game_slot_base", C.c_int), ("leaves_per_round", C.c_int),
-        ("c_in", C.c_int), ("c_out", C.c_int), ("value_dim", C.c_int),
+        ("c_in", C.c_int), ("c_out", C.c_int), ("value_dim", C.c_int), ("range_fallback", C.c_int),
+    ]
+
+
+class AzWeightsInfo(C.Structure):
+    _fields_ = [
+        ("precision_in_use", C.c_int), ("fell_back", C.c_int), ("overflow_weights", C.c_int64),
+        ("underflow_channels", C.c_int64), ("max_abs_weight", C.c_float), ("min_channel_max", C.c_float),
     ]
 
 
@@ -59,7 +66,7 @@ class AzStats(C.Structure):
         ("games", C.c_int64), ("replay_rows", C.c_int64), ("replay_dropped", C.c_int64),
         ("max_nodes", C.c_int32), ("max_edges", C.c_int32), ("error_games", C.c_int32), ("tree_restarts", C.c_int32),
         ("sims_backed_up", C.c_int64), ("descents", C.c_int64), ("tree_levels", C.c_int64),
-        ("children_scanned", C.c_int64), ("children_expanded", C.c_int64),
+        ("children_scanned", C.c_int64), ("children_expanded", C.c_int64), ("saturated", C.c_int64),
     ]
 
 
@@ -145,7 +152,8 @@ class Engine:
 
     def __init__(self, N, K, G, Cs=None, vl=3.0, c_puct=3.0, max_budget=800, node_cap=0,
                  eval_mode=AZ_EVAL_TOWER, noise_mode=AZ_NOISE_EXPLICIT, precision=AZ_PREC_FP16,
-                 seed=0, device=0, game_slot_base=0, leaves_per_round=1, c_in=0, c_out=0, value_dim=0):
+                 seed=0, device=0, game_slot_base=0, leaves_per_round=1, c_in=0, c_out=0, value_dim=0,
+                 range_fallback=0):
         L = load()
         cfg = AzConfig()
         cfg.device, cfg.N, cfg.K, cfg.G = device, N, K, G
@@ -159,6 +167,7 @@ class Engine:
         cfg.seed, cfg.game_slot_base = seed, game_slot_base
         cfg.leaves_per_round = leaves_per_round
         cfg.c_in, cfg.c_out, cfg.value_dim = c_in, c_out, value_dim
+        cfg.range_fallback = range_fallback
         self.c_in, self.c_out, self.value_dim = c_in or 3, c_out or 1, value_dim or 2
         self.L = max(1, leaves_per_round)
         self.N, self.K, self.G, self.A = N, K, G, N * N
@@ -183,6 +192,12 @@ class Engine:
 
     def load_weights_dev(self, dev_ptr, n_floats):
         _chk(load().az_load_weights_dev(self.h, C.c_void_p(dev_ptr), n_floats))
+
+    def weights_info(self):
+        """Where the last blob's folded weights sit in fp16's range and the operand format in use."""
+        w = AzWeightsInfo()
+        _chk(load().az_weights_info_get(self.h, C.byref(w)))
+        return {k: getattr(w, k) for k, _ in AzWeightsInfo._fields_}
 
     # -- PVNetwork::forward ------------------------------------------------
     def tower_forward(self, boards):

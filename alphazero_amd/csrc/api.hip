@@ -38,6 +38,9 @@ static int fail(int code, const char* fmt, ...) {
     return fail(AZ_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 #define AZCHK(call) do { int r_ = (call); if (r_ != AZ_OK) return r_; } while (0)
 #define NEED(ptr) do { if (!(ptr)) return fail(AZ_E_ARG, "null argument: %s", #ptr); } while (0)
+// entry points that touch per-game state: a tower-only context (see ctx_build) has none
+#define NEED_GAMES(c) do { if ((c)->tower_only) return fail(AZ_E_STATE, "this context is a tower only (c_in %d, c_out %d, " \
+    "value_dim %d): it holds no games and does not fit the m,n,k search", (c)->c_in, (c)->c_out, (c)->vd); } while (0)
 
 extern "C" const char* az_last_error(void) { return g_err.c_str(); }
 // for the library's other translation units (group.hip): record an error for az_last_error
@@ -61,7 +64,15 @@ struct az_ctx {
     unsigned short* conv_wf = nullptr;                    // [layer][tap][n=128][k=128] bf16, fused path
     bool fused = false;                                   // whole tower in one launch
     int conv_kind = 0;                                    // per-layer convolution kernel (az_conv_kind), fixed at creation
-    int prec = 0;                                         // 0 bf16, 1 fp16 operands
+    int prec = 0;                                         // 0 bf16, 1 fp16 operands (kernel template index) in use now
+    bool split = false;                                   // AZ_PREC_FP16X3: operands as hi + lo pairs, convolutions over 3x the channels
+    bool tower_only = false;                              // a tower whose shape no m,n,k search can use: no tree state allocated
+    unsigned short *catX = nullptr, *catH = nullptr;      // split: [rows][3 C_pad] = [hi | lo | hi] of the stream / the hidden activation
+    float* actS = nullptr;                                // split: fp32 image of a block's hidden activation
+    unsigned short* conv_w3 = nullptr;                    // split: [W_hi | W_hi | W_lo] images, 3x conv_w
+    int* d_range = nullptr;                               // [4] range tally of the fold's dry run (weights.hip)
+    unsigned long long* d_sat = nullptr;                  // [1] az_stats.saturated
+    az_weights_info winfo = {};
     unsigned short* conv_w = nullptr;                     // packed chunks, 2*num_res layers
     float* conv_b = nullptr;                              // [2*num_res][C_pad]
     float* head_p = nullptr;
@@ -137,8 +148,8 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
         for (int i = 1; i < cfg->n_Cs; ++i)
             if (cfg->Cs[i] != cfg->Cs[0])
                 return fail(AZ_E_ARG, "ResBlock widths must be uniform (x + input, network.hpp:36)");
-        if (cfg->precision != AZ_PREC_BF16 && cfg->precision != AZ_PREC_FP16)
-            return fail(AZ_E_ARG, "precision %d unknown (AZ_PREC_BF16, AZ_PREC_FP16)", cfg->precision);
+        if (cfg->precision != AZ_PREC_BF16 && cfg->precision != AZ_PREC_FP16 && cfg->precision != AZ_PREC_FP16X3)
+            return fail(AZ_E_ARG, "precision %d unknown (AZ_PREC_FP16, AZ_PREC_BF16, AZ_PREC_FP16X3)", cfg->precision);
         if (cfg->c_in < 0 || cfg->c_in > 16 || cfg->c_out < 0 || cfg->c_out > 128 || cfg->value_dim < 0 || cfg->value_dim > 8 || cfg->value_dim == 1)
             return fail(AZ_E_ARG, "tower shape out of range: c_in %d (<= 16), c_out %d (<= 128), value_dim %d (2..8)", cfg->c_in, cfg->c_out, cfg->value_dim);
     }
@@ -184,6 +195,14 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     d.vl = cfg->vl; d.c_puct_i = (int)cfg->c_puct;
     d.noise_mode = cfg->noise_mode; d.seed = cfg->seed; d.slot_base = cfg->game_slot_base;
     d.budget = mb;
+    // A tower whose planes / policy channels / value entries are not the m,n,k games' (3, 1, 2) serves
+    // az_tower_forward* only: none of the per-game tree, self-play and replay state below is allocated (at the
+    // Blokus evaluator's size, N = 20 and G = 2 048, that is about 4 GB of arenas and row buffers).
+    c->tower_only = cfg->eval_mode == AZ_EVAL_TOWER &&
+                    !((cfg->c_in == 0 || cfg->c_in == 3) && (cfg->c_out == 0 || cfg->c_out == 1) && (cfg->value_dim == 0 || cfg->value_dim == 2));
+    AZCHK(dalloc(c, &c->d_stats, 32)); AZCHK(dalloc(c, &c->d_illegal, 4));
+    AZCHK(dalloc(c, &c->d_range, 4)); AZCHK(dalloc(c, &c->d_sat, 2));
+  if (!c->tower_only) {
 #define DA(field, n) AZCHK(dalloc(c, &d.field, (size_t)(n)))
     DA(cells, (size_t)G * A); DA(to_move, G); DA(hist_len, G); DA(hist, (size_t)G * A);
     DA(game_over, G); DA(final_reward, 2 * (size_t)G);
@@ -211,10 +230,10 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         HIPCHK(hipMemcpy(d.noise, nz.data(), nz.size() * 4, hipMemcpyHostToDevice));
     }
     AZCHK(dalloc(c, &c->d_actions, G)); AZCHK(dalloc(c, &c->d_reward, 2 * (size_t)G));
-    AZCHK(dalloc(c, &c->d_done, G)); AZCHK(dalloc(c, &c->d_illegal, 4));
+    AZCHK(dalloc(c, &c->d_done, G));
     AZCHK(dalloc(c, &c->d_export, (size_t)G * 3 * A));
-    AZCHK(dalloc(c, &c->d_stats, 32));
     if (az_tree_configure(&d) != 0) return fail(AZ_E_HIP, "tree kernel LDS configuration failed (node_cap %d)", d.node_cap);
+  }
 
     c->Bmax = (int)S;
     if (cfg->eval_mode == AZ_EVAL_TOWER) {
@@ -222,11 +241,13 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         c->C_pad = (c->C + 127) / 128 * 128;
         c->num_res = cfg->n_Cs - 1;
         c->prec = cfg->precision == AZ_PREC_BF16 ? 0 : 1;           // kernel template index: 0 bf16, 1 fp16
+        c->split = cfg->precision == AZ_PREC_FP16X3;
+        c->winfo.precision_in_use = cfg->precision;
         c->c_in = cfg->c_in > 0 ? cfg->c_in : 3; c->c_out = cfg->c_out > 0 ? cfg->c_out : 1; c->vd = cfg->value_dim > 0 ? cfg->value_dim : 2;
         const bool mnk_shape = c->c_in == 3 && c->c_out == 1 && c->vd == 2;
         // whole tower in one launch when a board fits one 256-row LDS tile and the bias table of all
         // layers still fits beside it (160 KB per CU); otherwise one launch per convolution
-        c->fused = mnk_shape && c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED") &&
+        c->fused = mnk_shape && !c->split && c->C_pad == 128 && c->P <= 256 && !getenv("AZ_NO_FUSED") &&
                    az_tower_fused_lds_bytes(N, 2 * c->num_res, 256) <= 160 * 1024;
         c->conv_kind = az_conv_kind();
         c->conv_layer_elems = (size_t)(c->C_pad / 128) * (c->C_pad / 128) * 18 * 128 * 64;
@@ -246,6 +267,13 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
                 return fail(AZ_E_ARG, "tower heads do not fit LDS: c_out %d x %d channels, c_in %d", c->c_out, c->C_pad, c->c_in);
             AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * c->c_in * 9));
             AZCHK(dalloc(c, &c->conv_w, c->conv_layer_elems * 2 * c->num_res));
+            if (c->split) {
+                if (c->conv_kind != 0) return fail(AZ_E_ARG, "AZ_PREC_FP16X3 runs on the default per-layer kernel only (unset AZ_T256_32 / AZ_CONV_T128)");
+                AZCHK(dalloc(c, &c->catX, c->act_rows * c->C_pad * 3));
+                AZCHK(dalloc(c, &c->catH, c->act_rows * c->C_pad * 3));
+                AZCHK(dalloc(c, &c->actS, c->act_rows * c->C_pad));
+                AZCHK(dalloc(c, &c->conv_w3, c->conv_layer_elems * 3 * 2 * c->num_res));
+            }
             AZCHK(dalloc(c, &c->head_p, (size_t)(c->c_out + 1) * c->C_pad + c->c_out + 1 + 64 * (size_t)A + 64 + 64 * (size_t)c->vd + c->vd));
         }
         AZCHK(dalloc(c, &c->blob_stage, weights_size(N, c->c_in, c->c_out, c->vd, cfg->Cs, cfg->n_Cs), false));
@@ -304,6 +332,8 @@ static int load_weights_staged(az_ctx* c) {
     memset(&a, 0, sizeof a);
     a.blob = c->blob_stage; a.n_floats = az_weights_size(c);
     a.N = N; a.A = A; a.C = C; a.Cp = c->C_pad; a.nres = c->num_res;
+    // every load starts from the configured operand format (an earlier blob may have put the context on bf16)
+    c->prec = c->cfg.precision == AZ_PREC_BF16 ? 0 : 1;
     a.fused = c->fused ? 1 : 0; a.prec = c->prec; a.layer16 = c->conv_kind == 0;
     a.c_in = c->c_in; a.c_out = c->c_out; a.vd = c->vd;
     size_t o = 0;                                            // module registration order: CBlock, PHead, VHead, RBlock_i
@@ -317,6 +347,7 @@ static int load_weights_staged(az_ctx* c) {
     if (o + (size_t)c->num_res * a.res_stride != a.n_floats) return fail(AZ_E_STATE, "blob layout does not add up");
     a.stem_w = c->stem_w; a.stem_b = c->stem_b; a.stem_wbf = c->stem_wbf; a.conv_wf = c->conv_wf; a.conv_w = c->conv_w;
     a.conv_layer_elems = c->conv_layer_elems; a.conv_b = c->conv_b; a.head_p = c->head_p; a.head_pt = c->head_pt;
+    a.conv_w3 = c->conv_w3;
     // validate before anything is overwritten: a bad blob leaves the current weights in place
     HIPCHK(hipMemsetAsync(c->d_illegal, 0, 16, c->stream));
     az_launch_check_blob(c->stream, &a, c->d_illegal);
@@ -325,6 +356,28 @@ static int load_weights_staged(az_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (bad & 1) return fail(AZ_E_ARG, "weight blob holds non-finite values");
     if (bad & 2) return fail(AZ_E_ARG, "weight blob has a BatchNorm running_var + 1e-5 <= 0: its channel cannot be folded");
+    // where the folded weights sit in fp16's range: a dry run of the fold, still before anything is overwritten
+    {
+        const int init[4] = {0, 0, 0, 0x7F800000};
+        int rng[4];
+        HIPCHK(hipMemcpyAsync(c->d_range, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        az_launch_fold_range(c->stream, &a, c->d_range);
+        HIPCHK(hipMemcpyAsync(rng, c->d_range, sizeof rng, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        az_weights_info& wi = c->winfo;
+        wi.precision_in_use = c->cfg.precision; wi.fell_back = 0;
+        wi.overflow_weights = rng[0]; wi.underflow_channels = rng[1];
+        memcpy(&wi.max_abs_weight, &rng[2], 4); memcpy(&wi.min_channel_max, &rng[3], 4);
+        if (rng[3] == 0x7F800000) wi.min_channel_max = 0.f;
+        if (c->prec == 1 && (rng[0] > 0 || rng[1] > 0)) {
+            if (!c->cfg.range_fallback || c->split)
+                return fail(AZ_E_ARG, "folded weights leave fp16's range: %d beyond +-65504 (largest %.4g), %d output channels whose "
+                            "largest weight is below 2^-14 (smallest %.4g); load with AZ_PREC_BF16, or set az_config.range_fallback",
+                            rng[0], wi.max_abs_weight, rng[1], wi.min_channel_max);
+            c->prec = 0; a.prec = 0;                         // this blob runs on bf16 operands
+            wi.precision_in_use = AZ_PREC_BF16; wi.fell_back = 1;
+        }
+    }
     az_launch_fold(c->stream, &a);                           // padding entries of the images stay at their initial zero
     HIPCHK(hipGetLastError());
     c->have_weights = true;
@@ -350,6 +403,13 @@ extern "C" int az_load_weights_dev(az_ctx* c, const float* blob_dev, size_t n_fl
     return load_weights_common(c, blob_dev, n_floats, hipMemcpyDeviceToDevice);
 }
 
+extern "C" int az_weights_info_get(const az_ctx* c, az_weights_info* out) {
+    NEED(c); NEED(out);
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    *out = c->winfo;
+    return AZ_OK;
+}
+
 // ------------------------------------------------------------------- tower
 // actX / actH / actR: the activation images of the per-layer path ([guard + M_pad + guard][C_pad] rows, guard
 // and padding rows zero): 16-bit inputs of a block's two convolutions and the fp32 residual stream, which every
@@ -361,23 +421,46 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled, c->stream);
         az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
-                              c->head_pt, pol_dev, val_dev, B, N, Gd, 2 * c->num_res);
+                              c->head_pt, pol_dev, val_dev, B, N, Gd, 2 * c->num_res, c->d_sat);
         prof_end(c, on, c->stream);
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
     az_launch_stem(c->stream, c->prec, planes_dev, actX, actR, c->stem_w, c->stem_b, B, N, Cp, Gd, c->c_in);
+    if (c->split) {
+        // AZ_PREC_FP16X3.  Every operand is a pair hi + lo of fp16 values; conv(W, x) = W_hi x_hi + W_hi x_lo + W_lo x_hi
+        // as ONE reduction over three times the channels (activation rows [hi | lo | hi], weight image [W_hi | W_hi |
+        // W_lo], see az_cat3_kernel) on the per-layer path's own kernel.  The layer outputs are taken in fp32 (the
+        // residual form writes its sum back to the fp32 image it read: the residual stream for a block's second
+        // convolution, a zeroed image for its first) and re-split; the kernels' 16-bit outputs go unused.
+        const size_t M_pad = ((size_t)M + 255) / 256 * 256;
+        const size_t body = (size_t)Gd * Cp;                                      // the rows between the guards
+        az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
+        for (int i = 0; i < c->num_res; ++i) {
+            const unsigned short* w1 = c->conv_w3 + (size_t)(2 * i) * 3 * c->conv_layer_elems;
+            const unsigned short* w2 = w1 + 3 * c->conv_layer_elems;
+            const float* b1 = c->conv_b + (size_t)(2 * i) * Cp;
+            HIPCHK(hipMemsetAsync(c->actS + body, 0, M_pad * Cp * 4, c->stream));
+            az_launch_conv3x3(c->stream, c->prec, 0, c->catX, actH, c->actS, w1, b1, Cp, M, N, Gd, 1, 3 * Cp);
+            az_launch_cat3(c->stream, c->prec, c->actS + body, c->catH + 3 * body, M_pad, Cp);
+            az_launch_conv3x3(c->stream, c->prec, 0, c->catH, actX, actR, w2, b1 + Cp, Cp, M, N, Gd, 1, 3 * Cp);
+            az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
+        }
+        az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat);
+        HIPCHK(hipGetLastError());
+        return AZ_OK;
+    }
     for (int i = 0; i < c->num_res; ++i) {
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
         bool on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1, 0);
         prof_end(c, on, c->stream);
         on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1);
+        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1, 0);
         prof_end(c, on, c->stream);
     }
-    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd);
+    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat);
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }
@@ -429,6 +512,7 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
     NEED(c); NEED(boards_dev); NEED(policy_dev); NEED(value_dev);
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
     if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
+    if (c->split) return fail(AZ_E_STATE, "az_tower_forward_static does not run AZ_PREC_FP16X3 (its activation images are three times as wide; use az_tower_forward_dev)");
     HIPCHK(hipSetDevice(c->cfg.device));
     if (c->fused) {                                          // activations stay in LDS: nothing to place
         if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
@@ -453,7 +537,7 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
 
 // --------------------------------------------------------------------- env
 extern "C" int az_env_reset(az_ctx* c) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     az_launch_env_reset(c->stream, &c->d);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -461,7 +545,7 @@ extern "C" int az_env_reset(az_ctx* c) {
 }
 
 extern "C" int az_env_step(az_ctx* c, const int32_t* actions, float* reward, uint8_t* done) {
-    NEED(c); NEED(actions); NEED(reward); NEED(done);
+    NEED(c); NEED_GAMES(c); NEED(actions); NEED(reward); NEED(done);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
     HIPCHK(hipMemcpyAsync(c->d_actions, actions, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
@@ -477,7 +561,7 @@ extern "C" int az_env_step(az_ctx* c, const int32_t* actions, float* reward, uin
 }
 
 extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
-    NEED(c); NEED(planes);
+    NEED(c); NEED_GAMES(c); NEED(planes);
     HIPCHK(hipSetDevice(c->cfg.device));
     az_launch_env_export(c->stream, &c->d, c->d_export, nullptr);       // own scratch: never the evaluator's live input
     HIPCHK(hipMemcpyAsync(planes, c->d_export, (size_t)c->cfg.G * 3 * c->A, hipMemcpyDeviceToHost, c->stream));
@@ -486,7 +570,7 @@ extern "C" int az_env_boards(az_ctx* c, uint8_t* planes) {
 }
 
 extern "C" int az_env_legal_mask(az_ctx* c, uint8_t* mask) {
-    NEED(c); NEED(mask);
+    NEED(c); NEED_GAMES(c); NEED(mask);
     HIPCHK(hipSetDevice(c->cfg.device));
     az_launch_env_export(c->stream, &c->d, nullptr, c->d_export);
     HIPCHK(hipMemcpyAsync(mask, c->d_export, (size_t)c->cfg.G * c->A, hipMemcpyDeviceToHost, c->stream));
@@ -495,7 +579,7 @@ extern "C" int az_env_legal_mask(az_ctx* c, uint8_t* mask) {
 }
 
 extern "C" int az_env_set(az_ctx* c, const uint8_t* cells, const uint8_t* to_move) {
-    NEED(c); NEED(cells); NEED(to_move);
+    NEED(c); NEED_GAMES(c); NEED(cells); NEED(to_move);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, A = c->A;
     for (size_t i = 0; i < (size_t)G * A; ++i)
@@ -522,7 +606,7 @@ extern "C" int az_env_set(az_ctx* c, const uint8_t* cells, const uint8_t* to_mov
 // replayed on the host with the same rules, then uploaded with the history so
 // that find() (node.hpp:83-102) can reuse the tree.
 extern "C" int az_env_load(az_ctx* c, const int32_t* hist, const int32_t* hist_len) {
-    NEED(c); NEED(hist); NEED(hist_len);
+    NEED(c); NEED_GAMES(c); NEED(hist); NEED(hist_len);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, A = c->A, N = c->cfg.N;
     std::vector<uint8_t> cells((size_t)G * A, 0), tm(G, 0), over(G, 0);
@@ -553,7 +637,7 @@ extern "C" int az_env_load(az_ctx* c, const int32_t* hist, const int32_t* hist_l
 }
 
 extern "C" int az_set_noise(az_ctx* c, const float* noise) {
-    NEED(c); NEED(noise);
+    NEED(c); NEED_GAMES(c); NEED(noise);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(c->d.noise, noise, (size_t)c->cfg.G * c->A * 4, hipMemcpyHostToDevice));
@@ -561,7 +645,7 @@ extern "C" int az_set_noise(az_ctx* c, const float* noise) {
 }
 
 extern "C" int az_get_noise(az_ctx* c, float* noise) {
-    NEED(c); NEED(noise);
+    NEED(c); NEED_GAMES(c); NEED(noise);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipMemcpyAsync(noise, c->d.noise, (size_t)c->cfg.G * c->A * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -569,7 +653,7 @@ extern "C" int az_get_noise(az_ctx* c, float* noise) {
 }
 
 extern "C" int az_tree_clear(az_ctx* c) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
     {   // keep the arena high-water marks of the trees that are about to be dropped
@@ -630,7 +714,7 @@ static int check_budget(az_ctx* c, int budget, int searches_per_root) {
 }
 
 extern "C" int az_search_begin(az_ctx* c, int budget) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     AZCHK(check_budget(c, budget, 1));
     c->mode = AZ_MODE_SEARCH;
@@ -641,7 +725,7 @@ extern "C" int az_search_begin(az_ctx* c, int budget) {
 }
 
 extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "external evaluator: use az_search_select/apply");
     AZCHK(az_search_begin(c, budget));
     const int b = budget > 1 ? budget : 1;
@@ -675,7 +759,7 @@ extern "C" int az_search(az_ctx* c, int budget, float* out_policy) {
 }
 
 extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, int* n_running) {
-    NEED(c); NEED(planes); NEED(pending); NEED(n_running);
+    NEED(c); NEED_GAMES(c); NEED(planes); NEED(pending); NEED(n_running);
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G, L = c->d.L;
@@ -696,7 +780,7 @@ extern "C" int az_search_select(az_ctx* c, uint8_t* planes, int32_t* pending, in
 }
 
 extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* value) {
-    NEED(c); NEED(policy); NEED(value);
+    NEED(c); NEED_GAMES(c); NEED(policy); NEED(value);
     if (!c->search_active) return fail(AZ_E_STATE, "az_search_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t S = (size_t)c->cfg.G * c->d.L;
@@ -708,7 +792,7 @@ extern "C" int az_search_apply(az_ctx* c, const float* policy, const float* valu
 }
 
 extern "C" int az_search_result(az_ctx* c, float* out_policy, int32_t* root_n) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int G = c->cfg.G;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -726,7 +810,7 @@ extern "C" int az_search_result(az_ctx* c, float* out_policy, int32_t* root_n) {
 extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int32_t* n_nodes, int32_t* n_edges,
                             int32_t* node_first, int32_t* node_count, float* edge_p, int32_t* edge_n,
                             float* edge_v, int32_t* edge_child, int32_t* edge_action) {
-    NEED(c); NEED(n_nodes); NEED(n_edges);
+    NEED(c); NEED_GAMES(c); NEED(n_nodes); NEED(n_edges);
     if (game < 0 || game >= c->cfg.G) return fail(AZ_E_ARG, "game %d out of range", game);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -768,7 +852,7 @@ extern "C" int az_tree_dump(az_ctx* c, int game, int node_cap, int edge_cap, int
 
 // --------------------------------------------------------------- self-play
 extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     if (c->cfg.eval_mode == AZ_EVAL_EXTERNAL) return fail(AZ_E_STATE, "self-play needs a device evaluator");
     HIPCHK(hipSetDevice(c->cfg.device));
     AZCHK(check_budget(c, budget, 2));
@@ -788,7 +872,7 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
 }
 
 extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     if (c->mode != AZ_MODE_SELFPLAY) return fail(AZ_E_STATE, "az_selfplay_begin has not been called");
     HIPCHK(hipSetDevice(c->cfg.device));
     for (int r = 0; r < rounds; ++r) {
@@ -803,7 +887,7 @@ extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
 }
 
 extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
-    NEED(c);
+    NEED(c); NEED_GAMES(c);
     if (cap < 0) return fail(AZ_E_ARG, "cap %d is negative", cap);
     if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -839,12 +923,17 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     NEED(c); NEED(s);
     HIPCHK(hipSetDevice(c->cfg.device));
     // one reduction kernel behind the queued work and one 256-byte copy
-    unsigned long long k[32];
-    az_launch_stats(c->stream, &c->d, c->d_stats);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(k, c->d_stats, sizeof k, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long k[32], sat = 0;
+    memset(k, 0, sizeof k);
+    if (!c->tower_only) {
+        az_launch_stats(c->stream, &c->d, c->d_stats);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(k, c->d_stats, sizeof k, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(&sat, c->d_sat, sizeof sat, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     memset(s, 0, sizeof *s);
+    s->saturated = (int64_t)sat;
     s->sims = (int64_t)k[0]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
     s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
     s->rounds = c->rounds;

@@ -13,12 +13,16 @@ void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned sho
 int  az_conv_kind(void);                                          // per-layer convolution kernel (0, 1, 2), from the environment
 void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
                        float* resid, const unsigned short* wpk, const float* bias,
-                       int C_pad, int M, int N, int Gd, int relu);
+                       int C_pad, int M, int N, int Gd, int relu, int Cin /* channels of `in`, 0 = C_pad (kind 0 only) */);
 void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                            const float* stem_b, const unsigned short* wpk, const float* bias,
-                           const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers);
+                           const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,
+                           unsigned long long* sat);
+// sat: device counter of work items whose residual stream reached fp16's largest value (az_stats.saturated)
 void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
-                     float* value, int B, int N, int C_pad, int Gd, int c_out, int vd);
+                     float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat);
+// compensated mode: rows [hi | lo | hi] (3 C_pad 16-bit channels) from an fp32 image of `rows` x C_pad values
+void az_launch_cat3(hipStream_t s, int prec, const float* x, unsigned short* cat, size_t rows, int C_pad);
 size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out);     // dynamic LDS of az_heads_kernel / az_stem_kernel (<= 64 KB)
 size_t az_tower_stem_lds_bytes(int N, int C_pad, int c_in);
 }

@@ -683,7 +683,8 @@ template <int PR, bool RESID, bool RELU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
                        float* resid /* RESID: the fp32 residual stream, else unused */, const unsigned short* __restrict__ wpk,
-                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int xcd_tiles) {
+                       const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int xcd_tiles,
+                       int Cin /* channels (and row pitch) of `in` = the reduction's extent; C_pad except in the compensated mode */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = N + 1, P = W * W;
     const int rows_total = n_tiles * T4_M + 2 * Gd;          // rows of the activation buffers
@@ -711,8 +712,8 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
         if (slot / n_nb >= xcd_tiles || tile_i >= n_tiles) return;
     }
     const int m0 = tile_i * T4_M;
-    const int n_sc = C_pad / 128;
-    const int n_kc = C_pad / 64;
+    const int n_sc = Cin / 128;
+    const int n_kc = Cin / 64;
     const int total = n_kc * 9;                              // (slice, tap) chunks
 
     // acc[a][b][r]: position 64 wv + 16 b + 4 gc + r, channel 64 (a >> 2) + 4 lrc + (a & 3) of the block
@@ -732,15 +733,15 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
         wrsrc, (lds_void*)(w_dst + (buf_) * W2_BYTES + (it_) * 4096), 16, w_voff, (src_) + (it_) * 8192, 0, 0)
     // slab: DMA q covers rows 8q .. 8q+7 (lane: row 8q + (lane >> 3), physical piece lane & 7); wave w issues
     // q = w, w+4, ..., so (row >> 1) & 7 = 4 (w & 1) + (lane >> 4) is a per-lane constant
-    const size_t a_left = (size_t)(rows_total - m0) * C_pad * 2;
+    const size_t a_left = (size_t)(rows_total - m0) * Cin * 2;
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(in + (size_t)m0 * C_pad), 0, (int)(a_left < 0x7FFFFFFFull ? a_left : 0x7FFFFFFFull), 0x00020000);
-    const unsigned a_voff = (unsigned)((lane >> 3) * C_pad * 2 + (((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7)) << 4));
+        (void*)(in + (size_t)m0 * Cin), 0, (int)(a_left < 0x7FFFFFFFull ? a_left : 0x7FFFFFFFull), 0x00020000);
+    const unsigned a_voff = (unsigned)((lane >> 3) * Cin * 2 + (((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7)) << 4));
     const int n_q = slab_rows / 8;
 #define STAGE_A4(kc_) do { \
         for (int q_ = wvu; q_ < n_q; q_ += 4) \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sA + q_ * 1024), 16, \
-                                                     a_voff, q_ * 8 * C_pad * 2 + (kc_) * 128, 0, 0); \
+                                                     a_voff, q_ * 8 * Cin * 2 + (kc_) * 128, 0, 0); \
     } while (0)
 
 #pragma unroll
@@ -1144,7 +1145,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                       const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
                       const float* __restrict__ bias, const float* __restrict__ hp,
                       float* __restrict__ policy, float* __restrict__ value,
-                      int B, int N, int Gd, int n_layers, int bpt) {
+                      int B, int N, int Gd, int n_layers, int bpt, unsigned long long* __restrict__ sat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = 128 * J;                              // rows of the workgroup's tile
     constexpr int PW = 32 * J;                               // positions per wave
@@ -1334,6 +1335,16 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             for (int b = 0; b < NPB; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sp16[b][r] = (f32x2){0.f, 0.f};
+            // fp16 operands: a residual stream that reached the format's largest value was clamped on the way
+            // (relu_cap) -- count it, the answers of those boards are not the network's (az_stats.saturated)
+            if (PR == 1) {
+                float xm = 0.f;
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < NPB; ++b) xm = fmaxf(fmaxf(xm, fmaxf(X[a][b][0], X[a][b][1])), fmaxf(X[a][b][2], X[a][b][3]));
+                if (__ballot(xm >= 65504.f) != 0ull && lane == 0) atomicAdd(sat, 1ull);   // one per wave = 32 J positions
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float4 w01 = *(const float4*)(hp + 2 * (64 * q + 4 * lrc));          // {wp, wv} of channels c, c + 1
@@ -1461,7 +1472,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 template <int PR>
 __global__ void __launch_bounds__(256)
 az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const float* __restrict__ hp,
-                float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd, int c_out, int vd) {
+                float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd, int c_out, int vd,
+                unsigned long long* __restrict__ sat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int A = N * N, W = N + 1, P = W * W;
     const int MR = (c_out + 1 + 31) / 32 * 32;       // policy channels, then the value channel, padded to MFMA row blocks
@@ -1494,6 +1506,7 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     // The softmax's maximum and sum are kept as this lane's running (max, sum of exp(logit - max)) over the logits it
     // produces: the logits then cross the output buffer once (written here, rescaled in place below).
     float run_m = -3.4e38f, run_s = 0.f;
+    float xmax = 0.f;                                // largest value of the stream this lane read (fp16: saturation check)
     {
         typedef __attribute__((ext_vector_type(16))) float f32x16h;
         const int lane = tid & 63, wvi = tid >> 6, l31h = lane & 31, kh = lane >> 5;
@@ -1510,6 +1523,10 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
                     float4 xr[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) xr[q] = *(const float4*)(row + ch0 + 4 * q);
+                    if (PR == 1 && mb0 == 0) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) xmax = fmaxf(fmaxf(xmax, fmaxf(xr[q].x, xr[q].y)), fmaxf(xr[q].z, xr[q].w));
+                    }
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         if (mb0 + m >= MR / 32) continue;
@@ -1550,6 +1567,18 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
         }
     }
     __syncthreads();
+    // fp16 operands: a residual stream that reached the format's largest value was clamped on the way (relu_cap in
+    // the convolutions' epilogues): count the board, its answer is not the network's (az_stats.saturated)
+    if (PR == 1) {
+        s_red[tid] = xmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+            for (int i = 0; i < 256; ++i) m = fmaxf(m, s_red[i]);
+            if (m >= 65504.f) atomicAdd(sat, 1ull);
+        }
+        __syncthreads();
+    }
     // softmax over the c_out * A entries: combine the lanes' running pairs, then one pass over the logits
     const int n_pol = c_out * A;
     s_red[tid] = run_m;
@@ -1610,8 +1639,7 @@ extern "C" int az_tower_configure(void) {
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
-#define SETA4(pr) SETA((az_conv3x3_t256s_kernel<pr, false, false>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, false, true>), 80 * 1024); \
-                 SETA((az_conv3x3_t256s_kernel<pr, true, false>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, true, true>), 80 * 1024)
+#define SETA4(pr) SETA((az_conv3x3_t256s_kernel<pr, false, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, true, true>), 80 * 1024)
     SETA4(0); SETA4(1);
 #undef SETA4
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
@@ -1651,7 +1679,8 @@ extern "C" int az_conv_kind(void) {
 
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
                                   float* resid, const unsigned short* wpk, const float* bias,
-                                  int C_pad, int M, int N, int Gd, int relu) {
+                                  int C_pad, int M, int N, int Gd, int relu, int Cin) {
+    if (Cin <= 0) Cin = C_pad;                                           // the kernels of kinds 1 and 2 take square layers only
     if (kind != 2) {                                                      // 256 rows x 128 channels, two workgroups per CU
         const int tiles = (M + T4_M - 1) / T4_M;
         size_t sm = 2 * (size_t)W2_BYTES + (size_t)t4_slab_rows(Gd) * 128;
@@ -1661,9 +1690,10 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsig
         const dim3 grid = plain ? dim3(tiles, C_pad / 128) : dim3(8 * xcd_tiles * (C_pad / 128));
         if (kind == 0) {
 #define T4S_GO(pr, rs, rl) hipLaunchKernelGGL((az_conv3x3_t256s_kernel<pr, rs, rl>), grid, dim3(256), sm, s, \
-                                              in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, xcd_tiles)
-#define T4S_BY_FLAGS(pr) do { if (resid) { if (relu) T4S_GO(pr, true, true); else T4S_GO(pr, true, false); } \
-                              else { if (relu) T4S_GO(pr, false, true); else T4S_GO(pr, false, false); } } while (0)
+                                              in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, xcd_tiles, Cin)
+            // every 3x3 convolution of the tower is followed by a ReLU (network.hpp:33,36): the forms without one are
+            // not instantiated (relu is ignored here; the other two kernels take it at run time)
+#define T4S_BY_FLAGS(pr) do { if (resid) T4S_GO(pr, true, true); else T4S_GO(pr, false, true); } while (0)
             if (prec == 1) T4S_BY_FLAGS(1); else T4S_BY_FLAGS(0);
 #undef T4S_BY_FLAGS
 #undef T4S_GO
@@ -1680,7 +1710,8 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsig
 
 extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                                       const float* stem_b, const unsigned short* wpk, const float* bias,
-                                      const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers) {
+                                      const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,
+                                      unsigned long long* sat) {
     const int P = (N + 1) * (N + 1);
     // Tile height: 256 rows (four 16-position blocks per wave), or 128 rows where a whole board fits in 128
     // and the batch is too small to fill the chip with 256-row tiles.  A 128-row tile does half the MFMA
@@ -1696,7 +1727,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     const int bpt = rows / P;
     const int tiles = (B + bpt - 1) / bpt;
     const size_t sm = az_tower_fused_lds_bytes(N, n_layers, rows);
-#define FUSED_ARGS dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt
+#define FUSED_ARGS dim3(tiles), dim3(256), sm, s, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt, sat
 #define FUSED_LAUNCH(J_) do { if (prec == 1) hipLaunchKernelGGL((az_tower_fused_kernel<1, J_>), FUSED_ARGS); \
                               else hipLaunchKernelGGL((az_tower_fused_kernel<0, J_>), FUSED_ARGS); } while (0)
     if (rows == 128) FUSED_LAUNCH(1); else FUSED_LAUNCH(2);
@@ -1705,7 +1736,41 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
-                                float* value, int B, int N, int C_pad, int Gd, int c_out, int vd) {
+                                float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat) {
     const size_t sm = az_tower_heads_lds_bytes(N, C_pad, c_out);
-    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd, c_out, vd);
+    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd, c_out, vd, sat);
+}
+
+// Compensated mode of the per-layer path (AZ_PREC_FP16X3).  An activation x (fp32) enters a convolution as the pair
+// hi = 16-bit(x), lo = 16-bit(x - hi), 22 significant bits together, and conv(W, x) = W_hi * x_hi + W_hi * x_lo +
+// W_lo * x_hi (the lo * lo term is 2^-22 of the result) is ONE reduction over three times the channels: the input
+// image's rows are [hi | lo | hi] (3 C_pad channels), the weight image's [W_hi | W_hi | W_lo], and the convolution
+// kernel runs unchanged with Cin = 3 C_pad -- a single fp32 accumulation, the usual epilogue.  This kernel writes
+// that image from the fp32 one: rows x C_pad values in, rows x 3 C_pad out, eight values per thread.
+template <int PR>
+__global__ void __launch_bounds__(256) az_cat3_kernel(const float* __restrict__ x, unsigned short* __restrict__ cat, size_t rows, int C_pad) {
+    const size_t n8 = rows * (size_t)(C_pad / 8), stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const size_t r = i / (size_t)(C_pad / 8);
+        const int c8 = (int)(i - r * (size_t)(C_pad / 8)) * 8;
+        const float4 a = *(const float4*)(x + 8 * i), b = *(const float4*)(x + 8 * i + 4);
+        const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned short h0 = Prec<PR>::to16(xv[2 * k]), h1 = Prec<PR>::to16(xv[2 * k + 1]);
+            const unsigned short l0 = Prec<PR>::to16(xv[2 * k] - Prec<PR>::from16(h0)), l1 = Prec<PR>::to16(xv[2 * k + 1] - Prec<PR>::from16(h1));
+            h[k] = (unsigned)h0 | ((unsigned)h1 << 16);
+            l[k] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        unsigned short* row = cat + r * (size_t)(3 * C_pad) + c8;
+        *(uint4*)(row) = make_uint4(h[0], h[1], h[2], h[3]);
+        *(uint4*)(row + C_pad) = make_uint4(l[0], l[1], l[2], l[3]);
+        *(uint4*)(row + 2 * C_pad) = make_uint4(h[0], h[1], h[2], h[3]);
+    }
+}
+extern "C" void az_launch_cat3(hipStream_t s, int prec, const float* x, unsigned short* cat, size_t rows, int C_pad) {
+    const size_t n8 = rows * (size_t)(C_pad / 8);
+    const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    BY_PREC(az_cat3_kernel, dim3(blocks), dim3(256), 0, s, x, cat, rows, C_pad);
 }

@@ -53,26 +53,80 @@ __global__ void az_check_blob_kernel(AzFoldArgs a, int* bad) {
     if (flag) atomicOr(bad, flag);
 }
 
+__device__ __forceinline__ float w_from16(unsigned short h, int prec) {
+    if (prec == 1) return (float)__builtin_bit_cast(_Float16, h);
+    return __uint_as_float((unsigned)h << 16);
+}
+
+// Where the folded 16-bit weights of one output channel sit in fp16's range.  rng[0]: weights beyond +-65504 (the
+// image would hold a clamped value), rng[1]: channels whose largest folded weight is nonzero but below 2^-14 (every
+// weight of the row is an fp16 subnormal: less than 11 significant bits, down to none), rng[2] / rng[3]: largest
+// weight and smallest nonzero row maximum as float bits (positive floats order like integers).  Called by every
+// thread of a 256-thread block with its own (over, amax).
+__device__ __forceinline__ void range_tally(int over, float amax, int* rng) {
+    __shared__ int s_over[4];
+    __shared__ float s_max[4];
+    for (int o = 32; o > 0; o >>= 1) { over += __shfl_xor(over, o, 64); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_over[threadIdx.x >> 6] = over; s_max[threadIdx.x >> 6] = amax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ov = s_over[0] + s_over[1] + s_over[2] + s_over[3];
+        const float mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (ov) atomicAdd(rng, ov);
+        if (mx > 0.f && mx < 7.62939453125e-06f) atomicAdd(rng + 1, 1);
+        atomicMax(rng + 2, __float_as_int(mx));
+        if (mx > 0.f) atomicMin(rng + 3, __float_as_int(mx));
+    }
+    __syncthreads();
+}
+
 // grid (2 * nres, C): one block per (convolution, output channel); threads stride its C * 9 weights.
-__global__ void __launch_bounds__(256) az_fold_conv_kernel(AzFoldArgs a) {
+// rng != null: a dry run that only tallies the folded weights' range (nothing is written: a blob that is refused
+// leaves the images in use untouched).  a.part = 1 writes the compensated mode's image a.conv_w3 instead: three times
+// the input channels, [W_hi | W_hi | W_lo] with W_lo = 16-bit(w - W_hi), against activation rows [hi | lo | hi].
+__global__ void __launch_bounds__(256) az_fold_conv_kernel(AzFoldArgs a, int* rng) {
     const int L = blockIdx.x, co = blockIdx.y, C = a.C;
     const size_t wsz = (size_t)9 * C * C + C;
     const float* blk = a.blob + a.off_res0 + (size_t)(L >> 1) * a.res_stride;
     const float* w = blk + (size_t)(L & 1) * wsz;
     const float* bn = blk + 2 * wsz + (size_t)(L & 1) * 4 * C;
     const double s = bn_scale(bn, C, co);
-    if (threadIdx.x == 0) a.conv_b[(size_t)L * a.Cp + co] = bn_bias(bn, C, co, w[(size_t)9 * C * C + co], s);
+    if (threadIdx.x == 0 && !rng && !a.part) a.conv_b[(size_t)L * a.Cp + co] = bn_bias(bn, C, co, w[(size_t)9 * C * C + co], s);
     const int nblk = a.Cp / 128;
+    int over = 0;
+    float amax = 0.f;
     for (int e = threadIdx.x; e < C * 9; e += 256) {
         const int ci = e / 9, tap = e % 9;
-        const unsigned short v = w_to16((float)(w[(size_t)co * C * 9 + e] * s), a.prec);
-        if (a.fused)                                          // one 32 KB chunk per tap: [layer][tap][n][k]
+        const float f = (float)(w[(size_t)co * C * 9 + e] * s);
+        if (rng) { over += fabsf(f) > 65504.f; amax = fmaxf(amax, fabsf(f)); continue; }
+        const unsigned short v = w_to16(f, a.prec);
+        if (a.part) {                                         // [layer][nb][sc over 3 Cp][tap][n][k]
+            const unsigned short lo = w_to16(f - w_from16(v, a.prec), a.prec);
+            const int row = fused_row(co % 128);
+            for (int part = 0; part < 3; ++part) {
+                const size_t chunk = ((size_t)(co / 128) * 3 * nblk + part * nblk + ci / 128) * 9 + tap;
+                a.conv_w3[(size_t)L * 3 * a.conv_layer_elems + chunk * (128 * 128) + (size_t)row * 128 + ci % 128] = part == 2 ? lo : v;
+            }
+        } else if (a.fused)                                   // one 32 KB chunk per tap: [layer][tap][n][k]
             a.conv_wf[(((size_t)L * 9 + tap) * 128 + fused_row(co)) * 128 + ci] = v;
         else {                                                // [layer][nb][sc][tap][n][k]
             const size_t chunk = ((size_t)(co / 128) * nblk + ci / 128) * 9 + tap;
             const int row = a.layer16 ? fused_row(co % 128) : co % 128;
             a.conv_w[(size_t)L * a.conv_layer_elems + chunk * (128 * 128) + (size_t)row * 128 + ci % 128] = v;
         }
+    }
+    if (rng) range_tally(over, amax, rng);
+}
+
+// The stem's folded weights are 16-bit operands only in the fused kernel: one block, a row (output channel) at a time.
+__global__ void __launch_bounds__(256) az_range_stem_kernel(AzFoldArgs a, int* rng) {
+    const int C = a.C, KW = a.c_in * 9;
+    const float* sw = a.blob + a.off_stem_w;
+    const float* sbn = a.blob + a.off_stem_bn;
+    for (int co = 0; co < C; ++co) {
+        float f = 0.f;
+        if (threadIdx.x < KW) f = fabsf((float)(sw[co * KW + threadIdx.x] * bn_scale(sbn, C, co)));
+        range_tally(f > 65504.f, f, rng);
     }
 }
 
@@ -118,7 +172,17 @@ __global__ void __launch_bounds__(256) az_fold_small_kernel(AzFoldArgs a) {
 extern "C" void az_launch_check_blob(hipStream_t s, const AzFoldArgs* a, int* bad) {
     hipLaunchKernelGGL(az_check_blob_kernel, dim3(1024), dim3(256), 0, s, *a, bad);
 }
+// rng: int[4] on the device, {0, 0, 0, 0x7F800000} before the call (see range_tally)
+extern "C" void az_launch_fold_range(hipStream_t s, const AzFoldArgs* a, int* rng) {
+    hipLaunchKernelGGL(az_fold_conv_kernel, dim3(2 * a->nres, a->C), dim3(256), 0, s, *a, rng);
+    if (a->fused) hipLaunchKernelGGL(az_range_stem_kernel, dim3(1), dim3(256), 0, s, *a, rng);
+}
 extern "C" void az_launch_fold(hipStream_t s, const AzFoldArgs* a) {
-    hipLaunchKernelGGL(az_fold_conv_kernel, dim3(2 * a->nres, a->C), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(az_fold_conv_kernel, dim3(2 * a->nres, a->C), dim3(256), 0, s, *a, (int*)nullptr);
+    if (a->conv_w3) {
+        AzFoldArgs lo = *a;
+        lo.part = 1;
+        hipLaunchKernelGGL(az_fold_conv_kernel, dim3(2 * a->nres, a->C), dim3(256), 0, s, lo, (int*)nullptr);
+    }
     hipLaunchKernelGGL(az_fold_small_kernel, dim3(1), dim3(256), 0, s, *a);
 }

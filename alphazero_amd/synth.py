@@ -65,16 +65,56 @@ def blob_size(N, c_in, Cs, c_out=1, value_dim=2):
     return int(sum(int(np.prod(s)) for _, s in blob_layout(N, c_in, Cs, c_out, value_dim)))
 
 
-def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1, value_dim=2):
+def conv_layer_names(Cs):
+    """The BatchNorm-followed 3x3 convolutions in forward order with their BatchNorm: stem, then conv1 / conv2 of
+    every ResBlock."""
+    names = [("CBlock.conv", "CBlock.bn")]
+    for i in range(len(Cs) - 1):
+        names += [("RBlock_%d.conv1" % i, "RBlock_%d.bn1" % i), ("RBlock_%d.conv2" % i, "RBlock_%d.bn2" % i)]
+    return names
+
+
+def identity_calibration(Cs):
+    """bn_spread argument of make_blob that leaves the convolutions as drawn (what a calibration starts from)."""
+    n = 1 + 2 * (len(Cs) - 1)
+    return {"scale": np.ones((n, Cs[0]), np.float32), "shift": None, "vconv": (1.0, None)}
+
+
+def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1, value_dim=2, bn_spread=None):
     """Random-init weights: conv/linear U(-1/sqrt(fan_in), +), BN statistics
-    randomised so that folding is exercised; head gains sharpen the outputs."""
+    randomised so that folding is exercised; head gains sharpen the outputs.
+
+    bn_spread = None: benign BatchNorm (running_var in [0.5, 1.5], weight in [0.8, 1.2]).
+    bn_spread = dict: BatchNorm as trained networks have it -- running_var log-uniform over 1e-4 .. 1e2,
+    running_mean in +-3, weight in 0.01 .. 3 with about 3 % exact zeros, bias in +-0.5 -- and every convolution
+    in front of a BatchNorm rescaled per output channel (`scale` [layer][C], applied to the drawn weights) and
+    given the bias `shift` [layer][C] (None: the drawn one), `vconv` = (scale, shift) for VHead.conv.  With the
+    scales of a calibration (oracle/gen_golden.py: the pre-BatchNorm activations then have about the statistics
+    the BatchNorm holds, as after training) the network is well-conditioned; with identity_calibration() the
+    statistics are unrelated to the activations and the folded weights span six orders of magnitude."""
     parts = []
     off = 0
+    cal = {}
+    if bn_spread is not None:
+        for li, (cn, _) in enumerate(conv_layer_names(Cs)):
+            cal[cn] = (bn_spread["scale"][li], None if bn_spread["shift"] is None else bn_spread["shift"][li])
+        cal["VHead.conv"] = bn_spread["vconv"]
     for name, shape in blob_layout(N, c_in, Cs, c_out, value_dim):
         n = int(np.prod(shape))
         u = uniform01(seed, n, off)
         off += n
-        if name.endswith("running_var"):
+        spread = bn_spread is not None and ".bn" in name
+        if spread and name.endswith("running_var"):
+            x = 10.0 ** (-4.0 + 6.0 * u)
+        elif spread and name.endswith("running_mean"):
+            x = (u - 0.5) * 6.0
+        elif spread and name.endswith("weight"):
+            x = 0.01 + 2.99 * u
+            if not name.startswith("VHead"):
+                x[uniform01(seed + 7777, n, off) < 0.03] = 0.0          # channels the training switched off
+        elif spread and name.endswith("bias"):
+            x = u - 0.5
+        elif name.endswith("running_var"):
             x = 0.5 + u
         elif name.endswith("running_mean"):
             x = (u - 0.5) * 0.4
@@ -90,6 +130,13 @@ def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1, value_
             bound = 1.0 / np.sqrt(fan_in)
             x = (2.0 * u - 1.0) * bound
             prev_fan_in = fan_in
+            layer = name.rsplit(".", 1)[0]
+            if layer in cal:
+                sc, sh = cal[layer]
+                if name.endswith("weight"):
+                    x = (x.reshape(shape[0], -1) * np.asarray(sc, np.float64).reshape(-1, 1)).reshape(-1)
+                elif sh is not None:
+                    x = np.broadcast_to(np.asarray(sh, np.float64), (n,)).copy()
         if name == "PHead.conv.weight":
             x = x * phead_gain
         if name == "VHead.fc2.weight":
@@ -98,6 +145,17 @@ def make_blob(N, c_in, Cs, seed=0, phead_gain=1.0, fc2_gain=1.0, c_out=1, value_
             x = np.full(n, 0.5)
         parts.append(x.astype(np.float32))
     return np.concatenate(parts)
+
+
+def fixture_blob(z):
+    """The weights a tower fixture (tests/golden/tower_*.npz) was computed with, regenerated from its seed and,
+    for the fixtures with trained-network-like BatchNorm, the per-channel calibration the fixture carries."""
+    N, Cs = int(z["N"]), [int(c) for c in z["Cs"]]
+    c_in, c_out = (int(z["c_in"]), int(z["c_out"])) if "c_in" in z.files else (3, 1)
+    cal = None
+    if "calib_scale" in z.files:
+        cal = {"scale": z["calib_scale"], "shift": z["calib_shift"], "vconv": (float(z["calib_vconv"][0]), float(z["calib_vconv"][1]))}
+    return make_blob(N, c_in, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]), c_out=c_out, bn_spread=cal)
 
 
 def unpack_blob(blob, N, c_in, Cs, c_out=1, value_dim=2):

@@ -43,10 +43,18 @@ extern "C" {
 #define AZ_NOISE_EXPLICIT 0  /* Dirichlet noise from az_set_noise */
 #define AZ_NOISE_DEVICE   1  /* drawn on the device, alpha = 0.05 (util.h:42) */
 /* operand format of the tower's 3x3 convolutions (fp32 accumulate, fp32 residual stream, fp32 heads) */
-#define AZ_PREC_FP16     0   /* fp16 operands, saturating: the default; holds 1e-3 against the fp32 network
-                                (network.hpp:117-123) on peaked, trained-network-like outputs too */
+#define AZ_PREC_FP16     0   /* fp16 operands (11-bit significand), saturating: the default and the throughput mode.
+                                Within 1e-3 of the fp32 network (network.hpp:117-123) on random-init towers, also with
+                                sharpened heads, and on towers with trained-network-like BatchNorm and flat heads; a
+                                tower that is both (BatchNorm renormalising every layer, peaked policy) amplifies the
+                                operand rounding to 2e-3 .. 6e-3 on the policy */
 #define AZ_PREC_BF16     1   /* bf16 operands: same MFMA rate in cycles, ~4 % faster in wall time (lower power),
                                 8x coarser rounding: within 1e-3 only on flat (random-init) outputs */
+#define AZ_PREC_FP16X3   2   /* compensated fp16, the parity mode for deep or peaked towers: every operand is a pair
+                                hi + lo of fp16 values (22-bit significand) and every 3x3 convolution runs as three
+                                MFMA passes (hi*hi + hi*lo + lo*hi) into the fp32 accumulation, one launch per pass on
+                                the per-layer kernels: fp32-class agreement with network.hpp at about a third of the
+                                per-layer path's rate */
 
 typedef struct az_ctx az_ctx;
 
@@ -77,7 +85,22 @@ typedef struct az_config {
      * (network.hpp:73,81).  Other values (Blokus: 5, 91, 4) give a context whose tower is used through
      * az_tower_forward*; its m,n,k search entry points return AZ_E_STATE. */
     int   c_in, c_out, value_dim;
+    /* What az_load_weights does with a blob whose BatchNorm-folded weights leave fp16's range (one beyond +-65504, or
+     * an output channel whose largest weight is nonzero and below 2^-14) when the context runs fp16 operands: 0 =
+     * refuse it with AZ_E_ARG and keep the weights in use; 1 = take it with bf16 operands (fp32's range, 8-bit
+     * significand) and say so in az_weights_info.precision_in_use. */
+    int   range_fallback;
 } az_config;
+
+/* What the last az_load_weights* call on the context found and chose. */
+typedef struct az_weights_info {
+    int     precision_in_use;     /* AZ_PREC_* the tower's kernels run now */
+    int     fell_back;            /* 1: the blob left fp16's range and az_config.range_fallback put the context on bf16 */
+    int64_t overflow_weights;     /* folded 3x3 weights beyond +-65504 */
+    int64_t underflow_channels;   /* output channels whose largest folded weight is nonzero and below 2^-14 */
+    float   max_abs_weight;       /* largest folded 3x3 weight */
+    float   min_channel_max;      /* smallest nonzero per-channel maximum */
+} az_weights_info;
 
 typedef struct az_stats {
     int64_t sims;                 /* completed simulations (MCTS::count, mcts.hpp:170) */
@@ -99,6 +122,9 @@ typedef struct az_stats {
     int64_t tree_levels;          /* tree levels those descents walked (sum of path lengths) */
     int64_t children_scanned;     /* child edges read by __choose (mcts.hpp:350-381) on the way */
     int64_t children_expanded;    /* child edges written by _append_children (mcts.hpp:425-455) */
+    int64_t saturated;            /* tower tiles (one launch per evaluation) or boards (one launch per convolution) whose
+                                     residual stream reached the largest fp16 value, 65504, at the heads: the stream was
+                                     clamped on the way and those answers are not the network's.  0 with bf16 operands. */
 } az_stats;
 
 const char* az_last_error(void);
@@ -119,6 +145,9 @@ void* az_stream(az_ctx*);                          /* the hipStream_t all work i
 size_t az_weights_size(const az_ctx*);
 int az_load_weights(az_ctx*, const float* blob, size_t n_floats);
 int az_load_weights_dev(az_ctx*, const float* blob_dev, size_t n_floats);
+/* No counterpart in the reference (fp32 throughout): where the last blob's folded weights sit in fp16's range and
+ * the operand format the context runs as a result; also filled after a refused load. */
+int az_weights_info_get(const az_ctx*, az_weights_info*);
 
 /* Env::reset (generate.cpp:75), Env::step (mcts.hpp:251,261; generate.cpp:103),
  * Env::get_board (mcts.hpp:271), Env::possible_actions (mcts.hpp:427), batched

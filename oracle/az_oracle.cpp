@@ -224,28 +224,33 @@ extern "C" azo_tower* azo_tower_create(int N, int c_in, int c_out, const int* Cs
 }
 extern "C" void azo_tower_destroy(azo_tower* t) { delete t; }
 
-/* conv2d, stride 1, zero padding k/2, bias (network.hpp:12,27-28,48,70) */
+/* conv2d, stride 1, zero padding k/2, bias (network.hpp:12,27-28,48,70).  Every output is accumulated in
+ * double and rounded to fp32 once: the checker's own summation order then adds nothing, and libtorch's blocked
+ * fp32 summation stays within a few ulp of this.  (A sequential fp32 sum over 9 * C terms loses ~1e-5 absolute on an
+ * output near 3; in front of a BatchNorm with running_var 1e-4 that is 1e-3 of the normalised activation.) */
 static void conv2d(const ConvP& c, int N, const float* x, float* y) {
     const int A = N * N, pad = c.k / 2;
+    std::vector<double> acc(A);
     for (int co = 0; co < c.cout; ++co) {
-        float* yo = y + (size_t)co * A;
-        for (int i = 0; i < A; ++i) yo[i] = c.b[co];
+        for (int i = 0; i < A; ++i) acc[i] = c.b[co];
         for (int ci = 0; ci < c.cin; ++ci) {
             const float* xi = x + (size_t)ci * A;
             const float* w = c.w + ((size_t)co * c.cin + ci) * c.k * c.k;
             for (int ky = 0; ky < c.k; ++ky)
                 for (int kx = 0; kx < c.k; ++kx) {
-                    const float wv = w[ky * c.k + kx];
+                    const double wv = w[ky * c.k + kx];
                     const int dy = ky - pad, dx = kx - pad;
                     const int y0 = std::max(0, -dy), y1 = std::min(N, N - dy);
                     const int x0 = std::max(0, -dx), x1 = std::min(N, N - dx);
                     for (int yy = y0; yy < y1; ++yy) {
-                        float* yr = yo + yy * N;
+                        double* yr = acc.data() + yy * N;
                         const float* xr = xi + (yy + dy) * N + dx;
-                        for (int xx = x0; xx < x1; ++xx) yr[xx] += wv * xr[xx];
+                        for (int xx = x0; xx < x1; ++xx) yr[xx] += wv * (double)xr[xx];
                     }
                 }
         }
+        float* yo = y + (size_t)co * A;
+        for (int i = 0; i < A; ++i) yo[i] = (float)acc[i];
     }
 }
 /* BatchNorm2d eval mode, eps 1e-5 (network.hpp:13,29-30,71; evaluator.hpp:145) */

@@ -42,11 +42,93 @@ TOWER_CASES = [
     ("n3_cfg2", 3, synth.NETCONFIG2, 4, 7, 5.0, 5.0),
     # BASELINE configs[4]: 20 ResBlocks x 256 channels (41 convolutions deep), random-init and sharpened heads
     ("n15_c256x21", 15, [256] * 21, 8, 8, 1.0, 1.0),
-    ("n15_c256x21_sharp", 15, [256] * 21, 8, 9, 20.0, 20.0),
+    ("n15_c256x21_sharp", 15, [256] * 21, 256, 9, 20.0, 20.0),
     # the Blokus tower shape: 20x20 board, 5 input planes, 91 policy channels (network.hpp:104 `in`, `out`),
     # the reference's two-entry value head
     ("n20_in5_out91", 20, synth.NETCONFIG2, 2, 10, 6.0, 4.0, 5, 91),
 ]
+
+# Towers with BatchNorm as trained networks have it (synth.make_blob: bn_spread), convolutions calibrated so that
+# the pre-BatchNorm activations have about the statistics the BatchNorm holds; the heads' gains are set so that
+# the policy logits have standard deviation pl_std over a board and the two value logits differ by v_std.
+SPREAD_CASES = [
+    # name, N, Cs, B, weight seed, pl_std, v_std
+    ("n15_cfg2_spread", 15, synth.NETCONFIG2, 16, 21, 0.7, 0.3),
+    ("n15_cfg2_spread_sharp", 15, synth.NETCONFIG2, 16, 22, 3.0, 1.0),
+    ("n9_cfg2_spread_sharp", 9, synth.NETCONFIG2, 16, 23, 3.0, 1.0),
+    ("n15_c256x21_spread", 15, [256] * 21, 16, 24, 0.7, 0.3),
+    ("n15_c256x21_spread_sharp", 15, [256] * 21, 16, 25, 3.0, 1.0),
+]
+
+
+def calibrate(N, c_in, Cs, seed, boards, pl_std, v_std):
+    """Per-channel scale and bias of every convolution in front of a BatchNorm such that, on `boards`, its output
+    has mean = running_mean + j1 sqrt(running_var) and standard deviation = j2 sqrt(running_var) with seeded
+    j1 in +-0.5, j2 in 0.7 .. 1.4 (running statistics never match one batch exactly), and the two head gains."""
+    import torch
+    import torch.nn.functional as F
+    torch.set_num_threads(8)
+    cal = synth.identity_calibration(Cs)
+    w = {k: torch.from_numpy(v.copy()) for k, v in synth.unpack_blob(synth.make_blob(N, c_in, Cs, seed, bn_spread=cal), N, c_in, Cs).items()}
+    layers = synth.conv_layer_names(Cs)
+    scale = np.ones((len(layers), Cs[0]), np.float32)
+    shift = np.zeros((len(layers), Cs[0]), np.float32)
+
+    def fit(y0, bnn, li):
+        C = y0.shape[1]
+        m0 = y0.mean(dim=(0, 2, 3)).double().numpy()
+        s0 = np.maximum(y0.double().std(dim=(0, 2, 3)).numpy(), 1e-20)
+        rv, rm = w[bnn + ".running_var"].double().numpy(), w[bnn + ".running_mean"].double().numpy()
+        j1 = synth.uniform01(seed + 9000, C, 2 * li * 4096) - 0.5
+        j2 = 0.7 + 0.7 * synth.uniform01(seed + 9000, C, (2 * li + 1) * 4096)
+        sc = j2 * np.sqrt(rv) / s0
+        sh = rm + j1 * np.sqrt(rv) - sc * m0
+        return sc.astype(np.float32), sh.astype(np.float32)
+
+    def bn(y, n):
+        return F.batch_norm(y, w[n + ".running_mean"], w[n + ".running_var"], w[n + ".weight"], w[n + ".bias"], False, 0.0, 1e-5)
+
+    with torch.no_grad():
+        x = torch.from_numpy(boards.astype(np.float32))
+        h = None
+        for li, (cn, bnn) in enumerate(layers):
+            src = h if cn.endswith("conv2") else x
+            y0 = F.conv2d(src, w[cn + ".weight"], None, padding=1)
+            scale[li], shift[li] = fit(y0, bnn, li)
+            y = bn(y0 * torch.from_numpy(scale[li]).view(1, -1, 1, 1) + torch.from_numpy(shift[li]).view(1, -1, 1, 1), bnn)
+            if cn.endswith("conv2"):
+                x = F.relu(y + x)
+            elif cn.endswith("conv1"):
+                h = F.relu(y)
+            else:
+                x = F.relu(y)
+        print("   residual stream: max %.3g mean %.3g" % (float(x.max()), float(x.mean())))
+        logits = F.conv2d(x, w["PHead.conv.weight"], w["PHead.conv.bias"]).flatten(1)
+        pg = pl_std / float(logits.std(dim=1).mean())
+        v0 = F.conv2d(x, w["VHead.conv.weight"], None)
+        vsc, vsh = fit(v0, "VHead.bn", len(layers))
+        u = F.relu(bn(v0 * float(vsc[0]) + float(vsh[0]), "VHead.bn")).flatten(1)
+        f = F.relu(F.linear(u, w["VHead.fc1.weight"], w["VHead.fc1.bias"]))
+        z = F.linear(f, w["VHead.fc2.weight"], None)
+        fg = v_std / max(float((z[:, 0] - z[:, 1]).std()), 1e-12)
+    return {"scale": scale, "shift": shift, "vconv": (float(vsc[0]), float(vsh[0]))}, pg, fg
+
+
+def gen_tower_spread(name, N, Cs, B, wseed, pl_std, v_std):
+    boards = synth.random_boards(B, N, seed=wseed)
+    cal, pg, fg = calibrate(N, 3, Cs, wseed, boards, pl_std, v_std)
+    blob = synth.make_blob(N, 3, Cs, wseed, pg, fg, bn_spread=cal)
+    with tempfile.TemporaryDirectory() as d:
+        blob.tofile(os.path.join(d, "blob.bin"))
+        boards.tofile(os.path.join(d, "boards.bin"))
+        subprocess.check_call([REF, "tower", str(N), "3", os.path.join(d, "blob.bin"), os.path.join(d, "boards.bin"),
+                               str(B), os.path.join(d, "out")] + [str(c) for c in Cs])
+        pol = np.load(os.path.join(d, "out_policy.npy"))
+        val = np.load(os.path.join(d, "out_value.npy"))
+    np.savez_compressed(os.path.join(OUT, "tower_%s.npz" % name), N=N, Cs=np.array(Cs), B=B, wseed=wseed,
+                        phead_gain=pg, fc2_gain=fg, boards=boards, policy=pol, value=val, c_in=3, c_out=1,
+                        calib_scale=cal["scale"], calib_shift=cal["shift"], calib_vconv=np.array(cal["vconv"], np.float64))
+    print("tower", name, "pmax per board: median %.3g max %.3g" % (np.median(pol.max(1)), pol.max()), "v", val.min(), val.max())
 
 
 def gen_mcts(name, N, K, budget, n_moves, noise_seed, wseed):
@@ -82,6 +164,9 @@ if __name__ == "__main__":
     for c in TOWER_CASES:
         if not only or c[0] in only:
             gen_tower(*c)
+    for c in SPREAD_CASES:
+        if not only or c[0] in only:
+            gen_tower_spread(*c)
     for c in MCTS_CASES:
         if not only or c[0] in only:
             gen_mcts(*c)

@@ -37,16 +37,25 @@ def torch_reference(N, Cs, blob, boards, c_out=1, value_dim=2):
     return p.numpy(), v.numpy()
 
 
+# Fixture cases that miss the one 1e-3 bound, per operand format, as measured on the MI355X (strict: a case that
+# starts to pass, or a listed case that no longer exists, fails the suite).  fp16: the 41-convolution random-init
+# tower with heads sharpened 20x reaches 1.02e-3 on 2 of its 256 boards (median 3.6e-4), and the towers with
+# trained-network-like BatchNorm AND peaked heads amplify the operand rounding to 2e-3 .. 6e-3 (BatchNorm
+# renormalises every layer, so a perturbation grows from block to block; the fp32 reference itself sits 20-40x
+# further from an fp64 evaluation on them than on the random-init towers).  AZ_PREC_FP16X3 holds the bound on all.
+FP16_MISSES = {"tower_n15_c256x21_sharp", "tower_n15_c256x21_spread_sharp", "tower_n15_cfg2_spread_sharp", "tower_n9_cfg2_spread_sharp"}
+BF16_MISSES = FP16_MISSES | {"tower_n15_c256x21_spread", "tower_n15_cfg2_sharp", "tower_n15_cfg2_spread"}
+
+
 def _fixture_cases():
-    """Every reference fixture in both operand formats, ONE tolerance.  bf16 operands (8-bit significand) cannot
-    hold 1e-3 on the fixtures whose heads are sharpened (a trained-network-like peaked policy): those cases are
-    marked as expected failures of the opt-in bf16 mode, not given a looser bound.  fp16 is the library default."""
+    """Every reference fixture in the three operand formats against ONE tolerance."""
     cases = []
     for p in TOWER_FIX:
-        sharp = float(np.load(p)["phead_gain"]) > 1.0
-        for prec, name in ((capi.AZ_PREC_FP16, "fp16"), (capi.AZ_PREC_BF16, "bf16")):
-            marks = [pytest.mark.xfail(reason="bf16 operands miss 1e-3 on peaked outputs; opt-in mode, fp16 is the default",
-                                       strict=False)] if (sharp and name == "bf16") else []
+        stem = os.path.basename(p)[:-4]
+        for prec, name, misses in ((capi.AZ_PREC_FP16, "fp16", FP16_MISSES), (capi.AZ_PREC_BF16, "bf16", BF16_MISSES),
+                                   (capi.AZ_PREC_FP16X3, "fp16x3", set())):
+            marks = [pytest.mark.xfail(reason="%s operands miss 1e-3 on this tower (see FP16_MISSES); AZ_PREC_FP16X3 is the parity mode" % name,
+                                       strict=True)] if stem in misses else []
             cases.append(pytest.param(p, prec, id="%s-%s" % (os.path.basename(p), name), marks=marks))
     return cases
 
@@ -56,18 +65,102 @@ def test_tower_matches_reference_fixture(path, prec):
     z = np.load(path)
     N, Cs, B = int(z["N"]), [int(c) for c in z["Cs"]], int(z["B"])
     c_in, c_out = (int(z["c_in"]), int(z["c_out"])) if "c_in" in z.files else (3, 1)
-    blob = synth.make_blob(N, c_in, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]), c_out=c_out)
+    blob = synth.fixture_blob(z)
     eng = capi.Engine(N, min(N, 5), B, Cs=Cs, precision=prec, c_in=c_in, c_out=c_out, max_budget=1)
     eng.load_weights(blob)
     pol, val = eng.tower_forward(z["boards"])
     perr, verr = np.abs(pol - z["policy"]).max(), np.abs(val - z["value"]).max()
-    print(os.path.basename(path), "prec", prec, "policy err %.3g value err %.3g" % (perr, verr))
+    print(os.path.basename(path), "prec", prec, "policy err %.3g value err %.3g (max p %.3g)" % (perr, verr, z["policy"].max()))
     assert perr < TOL and verr < TOL
+    assert eng.stats()["saturated"] == 0
 
 
-def test_default_precision_is_the_parity_mode():
-    """A zero-initialised az_config / a default Engine runs fp16 operands, the mode that meets 1e-3 on every fixture."""
+def test_default_precision_is_fp16():
+    """A zero-initialised az_config / a default Engine runs fp16 operands."""
     assert capi.AZ_PREC_FP16 == 0 and capi.AzConfig().precision == capi.AZ_PREC_FP16
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_weights_outside_fp16_range_are_refused_or_fall_back(monkeypatch, fused):
+    """BatchNorm statistics unrelated to the activations (running_var down to 1e-4 under unit-scale convolutions)
+    fold into weights beyond +-65504, and a channel with a vanishing BatchNorm weight folds into a row of fp16
+    subnormals: az_load_weights refuses both with AZ_E_ARG and keeps the weights in use, says what it found in
+    az_weights_info, and with az_config.range_fallback takes the blob on bf16 operands instead."""
+    if not fused:
+        monkeypatch.setenv("AZ_NO_FUSED", "1")
+    N, B, Cs = 9, 6, synth.NETCONFIG2
+    good = synth.make_blob(N, 3, Cs, 77, phead_gain=5.0)
+    boards = synth.random_boards(B, N, seed=77)
+    lay, off = {}, 0
+    for name, shape in synth.blob_layout(N, 3, Cs):
+        lay[name] = (off, int(np.prod(shape)))
+        off += int(np.prod(shape))
+    over = good.copy()                                   # one channel: gamma / sqrt(var) = 3 / sqrt(1e-12 + 1e-5) ~ 950,
+    o, _ = lay["RBlock_2.bn1.running_var"]; over[o + 7] = 1e-12      # times a convolution scaled up 4000x
+    o, _ = lay["RBlock_2.bn1.weight"]; over[o + 7] = 3.0
+    o, n = lay["RBlock_2.conv1.weight"]; over[o + 7 * 1152:o + 8 * 1152] *= 4000.0
+    under = good.copy()                                  # one channel switched (almost) off: gamma = 1e-6
+    o, _ = lay["RBlock_5.bn2.weight"]; under[o + 100] = 1e-6
+    eng = capi.Engine(N, 5, B, Cs=Cs)
+    assert eng.tower_is_fused() == fused
+    eng.load_weights(good)
+    info = eng.weights_info()
+    assert info["overflow_weights"] == 0 and info["underflow_channels"] == 0 and info["precision_in_use"] == capi.AZ_PREC_FP16
+    assert 0 < info["min_channel_max"] <= info["max_abs_weight"] < 65504
+    p0, v0 = eng.tower_forward(boards)
+    with pytest.raises(capi.AzError, match="fp16's range"):
+        eng.load_weights(over)
+    assert eng.weights_info()["overflow_weights"] > 0
+    with pytest.raises(capi.AzError, match="fp16's range"):
+        eng.load_weights(under)
+    info = eng.weights_info()
+    assert info["underflow_channels"] == 1 and info["overflow_weights"] == 0
+    p1, v1 = eng.tower_forward(boards)                   # the weights loaded before are still in place
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+    # a bf16 context takes both (fp32's exponent range)
+    import torch
+    torch.set_num_threads(8)
+    eb = capi.Engine(N, 5, B, Cs=Cs, precision=capi.AZ_PREC_BF16)
+    eb.load_weights(under)
+    pb, vb = eb.tower_forward(boards)
+    # ... and so does an fp16 context with the fallback switched on: same bits as the bf16 context, and it says so
+    ef = capi.Engine(N, 5, B, Cs=Cs, range_fallback=1)
+    ef.load_weights(under)
+    info = ef.weights_info()
+    assert info["fell_back"] == 1 and info["precision_in_use"] == capi.AZ_PREC_BF16
+    pf, vf = ef.tower_forward(boards)
+    assert np.array_equal(pf, pb) and np.array_equal(vf, vb)
+    with torch.no_grad():
+        rp, rv = torch_reference(N, Cs, under, boards)
+    assert np.abs(pf - rp).max() < 5e-3 and np.abs(vf - rv).max() < 5e-3      # bf16's own accuracy, not the 1e-3 bar
+    ef.load_weights(good)                                # the next good blob is back on fp16
+    assert ef.weights_info()["precision_in_use"] == capi.AZ_PREC_FP16 and ef.weights_info()["fell_back"] == 0
+    pg, vg = ef.tower_forward(boards)
+    assert np.array_equal(pg, p0) and np.array_equal(vg, v0)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_saturated_residual_stream_is_counted(monkeypatch, fused):
+    """Weights inside fp16's range can still drive the ACTIVATIONS past 65504: the convolutions clamp there, the
+    heads see it in the residual stream and az_stats.saturated counts it."""
+    if not fused:
+        monkeypatch.setenv("AZ_NO_FUSED", "1")
+    N, B, Cs = 9, 6, synth.NETCONFIG2
+    blob = synth.make_blob(N, 3, Cs, 78)
+    lay, off = {}, 0
+    for name, shape in synth.blob_layout(N, 3, Cs):
+        lay[name] = (off, int(np.prod(shape)))
+        off += int(np.prod(shape))
+    eng = capi.Engine(N, 5, B, Cs=Cs)
+    eng.load_weights(blob)
+    eng.tower_forward(synth.random_boards(B, N, seed=78))
+    assert eng.stats()["saturated"] == 0
+    for i in range(3):                                   # every block's second BatchNorm amplifies by 300
+        o, n = lay["RBlock_%d.bn2.weight" % i]
+        blob[o:o + n] = 300.0
+    eng.load_weights(blob)
+    eng.tower_forward(synth.random_boards(B, N, seed=78))
+    assert eng.stats()["saturated"] > 0
 
 
 @pytest.mark.parametrize("prec", [capi.AZ_PREC_BF16, capi.AZ_PREC_FP16], ids=["bf16", "fp16"])
@@ -272,6 +365,9 @@ def test_blokus_shaped_tower_matches_torch_fp32(prec):
     assert np.allclose(pol.sum(1), 1.0, atol=1e-4) and np.allclose(val.sum(1), 2.0 - 4.0, atol=1e-5)
     with pytest.raises(capi.AzError, match="m,n,k search"):
         eng.search(1)                                   # this context is a tower, not an m,n,k searcher
+    with pytest.raises(capi.AzError, match="holds no games"):
+        eng.env_reset()
+    assert eng.stats()["sims"] == 0
 
 
 @pytest.mark.parametrize("c_in,c_out,vd,C", [(4, 2, 3, 192), (5, 100, 2, 128)], ids=["4in-2out-3val-192ch", "5in-100out-128ch"])

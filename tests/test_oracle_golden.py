@@ -41,12 +41,16 @@ def test_tower_restatement_matches_reference(path):
         B = 1     # the scalar restatement needs ~1 s per 15x15 board
     else:
         B = int(z["B"])
-    blob = synth.make_blob(N, c_in, Cs, int(z["wseed"]), float(z["phead_gain"]), float(z["fc2_gain"]), c_out=c_out)
+    blob = synth.fixture_blob(z)
     t = azo.Tower(N, c_in, Cs, blob, c_out=c_out)
     pol, val = t.forward(z["boards"][:B])
-    # fp32 vs fp32 with a different summation order: tolerance 2e-5 abs
-    assert np.abs(pol - z["policy"][:B]).max() < 2e-5
-    assert np.abs(val - z["value"][:B]).max() < 2e-5
+    # fp32 vs fp32 with a different summation order: tolerance 2e-5 abs.  The fixtures with trained-network-like
+    # BatchNorm (running_mean up to 300 standard deviations from zero) are ill-conditioned in fp32: `x - running_mean`
+    # cancels, and libtorch's own fp32 output sits 2e-5 .. 4.4e-5 from an fp64 evaluation of the same network
+    # (measured when the fixtures were made); those get 1e-4.
+    tol = 1e-4 if "calib_scale" in z.files else 2e-5
+    assert np.abs(pol - z["policy"][:B]).max() < tol
+    assert np.abs(val - z["value"][:B]).max() < tol
 
 
 def test_multi_leaf_order_reduces_to_single_thread_search():
