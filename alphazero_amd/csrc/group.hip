@@ -8,8 +8,10 @@
 //   * ncclCommInitAll over the group's GPUs; az_group_load_weights = one H2D copy on the first GPU,
 //     ncclBroadcast of the raw fp32 blob, BN fold + pack on every GPU (weights.hip) -- no host bounce
 //   * finished replay rows are drained per context and merged on the host in context order
-// RCCL is bound at run time (dlopen of librccl.so.1, the copy already mapped if there is one), so the
-// library itself has no link-time dependency on it and single-GPU users never load it.
+// RCCL is bound at run time (dlopen of librccl.so.1, the copy already mapped if there is one; AZ_RCCL_LIB names
+// another file), and only by a group of more than one GPU: the library has no link-time dependency on it, and a
+// one-GPU group -- what the generator is on a single-GPU box -- neither loads it nor creates a communicator: its
+// blob goes host -> device and is folded there.
 #include "../../include/az_hip.h"
 
 #include <dlfcn.h>
@@ -17,6 +19,7 @@
 
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -42,8 +45,10 @@ struct Rccl {
     bool load() {
         if (so) return true;
         const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
-        if (!so) { why = std::string("librccl not found: ") + dlerror(); return false; }
+        const char* forced = getenv("AZ_RCCL_LIB");
+        if (forced) so = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        else for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
+        if (!so) { const char* de = dlerror(); why = std::string("librccl not found: ") + (de ? de : "?"); return false; }
 #define BIND(field, sym) do { *(void**)(&field) = dlsym(so, sym); if (!field) { why = std::string("missing RCCL symbol ") + sym; return false; } } while (0)
         BIND(CommInitAll, "ncclCommInitAll"); BIND(CommDestroy, "ncclCommDestroy"); BIND(GroupStart, "ncclGroupStart");
         BIND(GroupEnd, "ncclGroupEnd"); BIND(Broadcast, "ncclBroadcast"); BIND(GetErrorString, "ncclGetErrorString");
@@ -151,7 +156,7 @@ extern "C" int az_group_create(az_group** out, const az_config* cfg, const int* 
     for (int i = 0; i < n_devices; ++i)
         for (int j = 0; j < i; ++j)
             if (devices[i] == devices[j]) return gfail(AZ_E_ARG, "device " + std::to_string(devices[i]) + " listed twice");
-    {
+    if (n_devices > 1) {                                         // a one-GPU group has nothing to broadcast to
         std::lock_guard<std::mutex> lk(g_rccl_mu);
         if (!g_rccl.load()) return gfail(AZ_E_HIP, g_rccl.why);
     }
@@ -177,8 +182,10 @@ extern "C" int az_group_create(az_group** out, const az_config* cfg, const int* 
         if (e == hipSuccess && g->n_floats) e = hipMalloc((void**)&g->blob_dev[(size_t)d], g->n_floats * sizeof(float));
         if (e != hipSuccess) { az_group_destroy(g); return gfail(AZ_E_HIP, std::string("blob buffer: ") + hipGetErrorString(e)); }
     }
-    const int nr = g_rccl.CommInitAll(g->comms.data(), n_devices, devices);
-    if (nr != 0) { const std::string m = g_rccl.GetErrorString(nr); az_group_destroy(g); return gfail(AZ_E_HIP, "ncclCommInitAll failed: " + m); }
+    if (n_devices > 1) {
+        const int nr = g_rccl.CommInitAll(g->comms.data(), n_devices, devices);
+        if (nr != 0) { const std::string m = g_rccl.GetErrorString(nr); az_group_destroy(g); return gfail(AZ_E_HIP, "ncclCommInitAll failed: " + m); }
+    }
     for (int d = 0; d < n_devices; ++d) g->workers.push_back(new Worker);
     *out = g;
     return AZ_OK;
@@ -198,13 +205,15 @@ extern "C" int az_group_load_weights(az_group* g, const float* blob, size_t n_fl
     hipStream_t s0 = (hipStream_t)az_stream(g->ctxs[0]);
     GHIP(hipMemcpyAsync(g->blob_dev[0], blob, n_floats * sizeof(float), hipMemcpyHostToDevice, s0));
     // ... and reaches every other GPU over xGMI: one broadcast, each GPU on its own first context's stream
-    GNCCL(g_rccl.GroupStart());
-    for (int d = 0; d < nd; ++d) {
-        hipStream_t s = (hipStream_t)az_stream(g->ctxs[(size_t)d * g->per_device]);
-        const int r = g_rccl.Broadcast(g->blob_dev[(size_t)d], g->blob_dev[(size_t)d], n_floats, NCCL_FLOAT32, 0, g->comms[(size_t)d], s);
-        if (r != 0) { g_rccl.GroupEnd(); return gfail(AZ_E_HIP, std::string("ncclBroadcast failed: ") + g_rccl.GetErrorString(r)); }
+    if (nd > 1) {
+        GNCCL(g_rccl.GroupStart());
+        for (int d = 0; d < nd; ++d) {
+            hipStream_t s = (hipStream_t)az_stream(g->ctxs[(size_t)d * g->per_device]);
+            const int r = g_rccl.Broadcast(g->blob_dev[(size_t)d], g->blob_dev[(size_t)d], n_floats, NCCL_FLOAT32, 0, g->comms[(size_t)d], s);
+            if (r != 0) { g_rccl.GroupEnd(); return gfail(AZ_E_HIP, std::string("ncclBroadcast failed: ") + g_rccl.GetErrorString(r)); }
+        }
+        GNCCL(g_rccl.GroupEnd());
     }
-    GNCCL(g_rccl.GroupEnd());
     // every GPU folds and packs its own copy (weights.hip), all contexts of the GPU from the same blob
     return on_every_device(g, [g, n_floats](int d) {
         hipError_t e = hipSetDevice(g->devices[(size_t)d]);
@@ -301,6 +310,7 @@ extern "C" int az_group_get_stats(az_group* g, az_stats* out) {
         out->error_games += s.error_games; out->tree_restarts += s.tree_restarts; out->sims_backed_up += s.sims_backed_up;
         out->descents += s.descents; out->tree_levels += s.tree_levels;
         out->children_scanned += s.children_scanned; out->children_expanded += s.children_expanded;
+        out->saturated += s.saturated;
         out->rounds = s.rounds > out->rounds ? s.rounds : out->rounds;
         out->max_nodes = s.max_nodes > out->max_nodes ? s.max_nodes : out->max_nodes;
         out->max_edges = s.max_edges > out->max_edges ? s.max_edges : out->max_edges;

@@ -220,6 +220,38 @@ def test_search_with_the_tower_as_evaluator():
     assert dev.search_stats()["restarts"] == 0
 
 
+def test_config3_search_2048_games_400_sims_with_the_tower():
+    """BASELINE configs[3] as bench.py --config 3 runs it: 2048 Blokus games x 400 simulations with the tower
+    (10 x 128 channels, 5 planes in, 91 policy channels, 4 values) as evaluator, nothing leaving the device
+    between the rounds: every root holds exactly 400 visits over its legal actions, no tree outgrew its arena,
+    and for a sample of games the root's priors are the tower's softmax at the legal actions, bit for bit."""
+    from alphazero_amd import synth
+    G, budget = 2048, 400
+    Cs = synth.NETCONFIG2
+    dev = capi.Blokus(G, seed=78)
+    dev.search_config(max_budget=budget)
+    dev.playout(9)
+    dev.sync()
+    tower = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    tower.load_weights(synth.make_blob(20, 5, Cs, 31, phead_gain=4.0, fc2_gain=2.0, c_out=91, value_dim=4))
+    dev.search_tower(tower, budget)
+    st = dev.search_stats()
+    _, count = dev.legal_mask(want_mask=False)
+    print("blokus 2048 x 400 with the tower:", st)
+    assert st["restarts"] == 0 and st["max_nodes"] <= budget + 1
+    sample = list(range(0, G, 131))
+    boards = dev.boards()
+    pol, _ = tower.tower_forward(boards[sample])
+    for k, g in enumerate(sample):
+        r = dev.search_result(g)
+        assert r["root_n"] == budget + 1 and r["n"].sum() == budget and len(r["actions"]) == count[g]
+        assert (np.diff(r["actions"]) > 0).all() and (r["n"] >= 0).all()
+        assert np.array_equal(r["p"], pol[k, r["actions"]])
+        vis = r["n"] > 0
+        assert (np.abs(r["v"][vis] / r["n"][vis]) <= 1.0 + 1e-6).all() and (r["v"][~vis] == 0).all()
+    assert tower.stats()["saturated"] == 0
+
+
 def _game_blocks(rows_planes, per_row):
     """split rows (oldest first, each game's rows contiguous) into games at the empty-board rows"""
     blocks, cur = [], []

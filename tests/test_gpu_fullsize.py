@@ -66,6 +66,40 @@ def test_config1_gomoku9_256games_400sims_hash_evaluator():
         assert not done.any()
 
 
+def test_config1_gomoku9_256games_400sims_tower():
+    """configs[1] as bench.py --config 1 runs it: gomoku 9x9, 256 games x 400 sims/move with the NetConfig-2 tower as
+    evaluator (the fused kernel in 128-row tiles, one board per tile)."""
+    N, K, G, budget = 9, 5, 256, 400
+    Cs = synth.NETCONFIG2
+    eng = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=7)
+    assert eng.tower_is_fused()
+    eng.load_weights(synth.make_blob(N, 3, Cs, 0, phead_gain=8.0, fc2_gain=4.0))
+    eng.env_reset()
+    out = eng.search(budget)
+    assert np.isfinite(out).all()
+    assert np.allclose(out.sum(1), 400.0 / 401.0, atol=2e-5)      # fresh roots: n = 1 + 400 (mcts.hpp:413, Q10)
+    for g in (0, 100, 255):
+        tree_invariants(eng, g, 401)
+    # the root's priors are the tower's softmax of the empty board mixed with the device's Dirichlet draw (Q8)
+    pol, _ = eng.tower_forward(eng.env_boards()[:4])
+    noise = eng.get_noise()
+    for g in range(4):
+        d = eng.tree_dump(g)
+        k = int(d["node_count"][0])
+        want = (0.75 * pol[g].astype(np.float64) + 0.25 * noise[g, :k].astype(np.float64)).astype(np.float32)
+        assert np.array_equal(d["p"][:k], want)
+    acts = out.argmax(1).astype(np.int32)
+    n_child = np.rint(out.max(1) * 401).astype(int)
+    eng.env_step(acts)
+    out2 = eng.search(budget)                                      # roots reused: n grows by exactly 400
+    for g in (0, 100, 255):
+        tree_invariants(eng, g, int(n_child[g]) + 400)
+        assert abs(out2[g].sum() - (n_child[g] + 399) / (n_child[g] + 400)) < 2e-5
+        assert out2[g][acts[g]] == 0
+    st = eng.stats()
+    assert st["error_games"] == 0 and st["saturated"] == 0 and st["tree_restarts"] == 0
+
+
 def test_config2_gomoku15_512games_800sims_tower():
     """configs[2] per-GPU shard: gomoku 15x15, 512 games x 800 sims/move, NetConfig-2 tower."""
     N, K, G, budget = 15, 5, 512, 800

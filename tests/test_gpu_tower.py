@@ -391,3 +391,25 @@ def test_odd_plane_and_channel_counts_match_torch_fp32(c_in, c_out, vd, C):
     print("odd-shaped tower: policy err %.3g (max p %.3g) value err %.3g" % (np.abs(pol - rp).max(), rp.max(), np.abs(val - rv).max()))
     assert np.abs(pol - rp).max() < TOL and np.abs(val - rv).max() < TOL
     assert np.allclose(pol.sum(1), 1.0, atol=1e-4)
+
+
+def test_blokus_shaped_tower_at_batch_2048_matches_the_reference_fixture():
+    """The Blokus evaluator at BASELINE configs[3]'s batch: 2048 boards of 20x20 with 5 planes, 91 policy channels.
+    The first boards are those of the reference fixture (the unmodified network.hpp with in = 5, out = 91): 1e-3 at
+    the full batch; the rest through properties: every policy a distribution over the 36 400 entries, and a
+    permutation of the batch permutes the outputs bit for bit."""
+    z = np.load(os.path.join(GOLDEN, "tower_n20_in5_out91.npz"))
+    N, Cs, nb, B = int(z["N"]), [int(c) for c in z["Cs"]], int(z["B"]), 2048
+    blob = synth.fixture_blob(z)
+    planes = synth.random_planes(B, 5, N, seed=2048)
+    planes[:nb] = z["boards"]
+    eng = capi.Engine(N, 5, B, Cs=Cs, c_in=5, c_out=91, max_budget=1)
+    eng.load_weights(blob)
+    pol, val = eng.tower_forward(planes)
+    assert np.abs(pol[:nb] - z["policy"]).max() < TOL and np.abs(val[:nb] - z["value"]).max() < TOL
+    assert np.isfinite(pol).all() and (pol >= 0).all() and np.abs(pol.sum(1) - 1.0).max() < 1e-4
+    assert np.abs(val.sum(1)).max() < 1e-6
+    perm = np.random.default_rng(6).permutation(B)[:32]
+    polp, valp = eng.tower_forward(planes[perm])
+    assert np.array_equal(polp, pol[perm]) and np.array_equal(valp, val[perm])
+    assert eng.stats()["saturated"] == 0
