@@ -13,6 +13,7 @@
 // one-GPU group -- what the generator is on a single-GPU box -- neither loads it nor creates a communicator: its
 // blob goes host -> device and is folded there.
 #include "../../include/az_hip.h"
+#include "az_worker.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -60,52 +61,6 @@ Rccl g_rccl;
 std::mutex g_rccl_mu;
 enum { NCCL_FLOAT32 = 7 };                                        // ncclFloat32 (rccl.h)
 
-// A host thread bound to one GPU: runs the jobs it is handed in order.
-class Worker {
-public:
-    Worker() : th_([this] { loop(); }) {}
-    ~Worker() {
-        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
-        cv_.notify_all();
-        th_.join();
-    }
-    void post(std::function<int()> job) {
-        { std::lock_guard<std::mutex> lk(mu_); job_ = std::move(job); busy_ = true; }
-        cv_.notify_all();
-    }
-    // returns the job's status; its error text (az_last_error is per thread) comes back in `msg`
-    int wait(std::string& msg) {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [this] { return !busy_; });
-        msg = msg_;
-        return rc_;
-    }
-private:
-    void loop() {
-        for (;;) {
-            std::function<int()> job;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return quit_ || (busy_ && job_); });
-                if (quit_) return;
-                job = std::move(job_);
-                job_ = nullptr;
-            }
-            const int rc = job();
-            const std::string m = rc < 0 ? az_last_error() : "";
-            { std::lock_guard<std::mutex> lk(mu_); rc_ = rc; msg_ = m; busy_ = false; }
-            cv_.notify_all();
-        }
-    }
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::function<int()> job_;
-    bool busy_ = false, quit_ = false;
-    int rc_ = 0;
-    std::string msg_;
-    std::thread th_;
-};
-
 }  // namespace
 
 struct az_group {
@@ -114,7 +69,7 @@ struct az_group {
     std::vector<az_ctx*> ctxs;                  // [device][slot], device-major
     std::vector<nccl_comm_t> comms;             // one per device
     std::vector<float*> blob_dev;               // one fp32 blob per device: the broadcast's buffer
-    std::vector<Worker*> workers;               // one per device
+    std::vector<az_worker::Worker*> workers;               // one per device
     size_t n_floats = 0;
 };
 
@@ -139,7 +94,7 @@ static int on_every_device(az_group* g, const std::function<int(int)>& job) {
 
 extern "C" int az_group_destroy(az_group* g) {
     if (!g) return AZ_OK;
-    for (Worker* w : g->workers) delete w;                       // joins: no launch is in flight on the host side
+    for (az_worker::Worker* w : g->workers) delete w;                       // joins: no launch is in flight on the host side
     for (az_ctx* c : g->ctxs) az_ctx_destroy(c);
     for (size_t d = 0; d < g->comms.size(); ++d) if (g->comms[d]) g_rccl.CommDestroy(g->comms[d]);
     for (size_t d = 0; d < g->blob_dev.size(); ++d)
@@ -186,7 +141,7 @@ extern "C" int az_group_create(az_group** out, const az_config* cfg, const int* 
         const int nr = g_rccl.CommInitAll(g->comms.data(), n_devices, devices);
         if (nr != 0) { const std::string m = g_rccl.GetErrorString(nr); az_group_destroy(g); return gfail(AZ_E_HIP, "ncclCommInitAll failed: " + m); }
     }
-    for (int d = 0; d < n_devices; ++d) g->workers.push_back(new Worker);
+    for (int d = 0; d < n_devices; ++d) g->workers.push_back(new az_worker::Worker(az_last_error));
     *out = g;
     return AZ_OK;
 }
