@@ -441,9 +441,13 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
             const unsigned short* w2 = w1 + 3 * c->conv_layer_elems;
             const float* b1 = c->conv_b + (size_t)(2 * i) * Cp;
             HIPCHK(hipMemsetAsync(c->actS + body, 0, M_pad * Cp * 4, c->stream));
+            bool on = prof_begin(c, 0, sampled, c->stream);
             az_launch_conv3x3(c->stream, c->prec, 0, c->catX, actH, c->actS, w1, b1, Cp, M, N, Gd, 1, 3 * Cp);
+            prof_end(c, on, c->stream);
             az_launch_cat3(c->stream, c->prec, c->actS + body, c->catH + 3 * body, M_pad, Cp);
+            on = prof_begin(c, 0, sampled, c->stream);
             az_launch_conv3x3(c->stream, c->prec, 0, c->catH, actX, actR, w2, b1 + Cp, Cp, M, N, Gd, 1, 3 * Cp);
+            prof_end(c, on, c->stream);
             az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
         }
         az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat);

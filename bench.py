@@ -63,6 +63,132 @@ def cpu_baseline(seconds, N, K, budget, nthreads):
             "sample": "scalar C++ restatement, %dx%d, %d sims in %.1f s" % (N, N, sims, el)}
 
 
+def other_configs(device):
+    """Short legs of the other BASELINE.json configurations, after the headline and outside its timed region, so
+    that one record covers every config: each {workload, value, unit, roofline} with the dominant kernel's HIP-event
+    launch time and FLOPs of real board cells per launch."""
+    from alphazero_amd import capi, synth
+    import torch
+    out = []
+    Cs = synth.NETCONFIG2
+
+    def roof(kernel, flops, prof, hbm_bytes=None):
+        us = prof["conv_avg_us"]
+        tf = flops / (us * 1e-6) / 1e12 if us > 0 else 0.0
+        r = {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": tf / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": us, "launches_sampled": prof["conv_launches"],
+             "flops_per_launch": flops, "traffic": None}
+        if hbm_bytes is not None and us > 0:
+            r["algorithmic_hbm_gbs"] = hbm_bytes / (us * 1e-6) / 1e9
+            r["algorithmic_hbm_frac"] = r["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
+        return r
+
+    # configs[1]: gomoku 9x9, 256 games x 400 sims/move, self-play with the fused tower in 128-row tiles
+    N, G, budget, moves = 9, 256, 400, 30
+    eng = capi.Engine(N, 5, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0, device=device)
+    eng.load_weights(synth.make_blob(N, 3, Cs, 0))
+    eng.selfplay_begin(budget)
+    eng.selfplay_run(3 * budget)
+    eng.profile_enable(max(1, moves * budget * 2 // 3600))
+    eng.sync()
+    s0 = eng.stats()["sims_backed_up"]
+    t0 = time.perf_counter()
+    eng.selfplay_run(moves * budget)
+    eng.sync()
+    el = time.perf_counter() - t0
+    st = eng.stats()
+    prof = eng.profile_read()
+    A, C = N * N, Cs[0]
+    out.append({"config": 1, "workload": "gomoku 9x9 self-play, 256 concurrent games, 400 sims/move, NetConfig-2 tower, fp16 operands",
+                "value": (st["sims_backed_up"] - s0) / el, "unit": "sims/s", "seconds": el, "ms_per_round": el / (moves * budget) * 1e3,
+                "roofline": roof("az_tower_fused_kernel", (2.0 * 9 * A * C * C * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C) * G, prof),
+                "tree_round_avg_us": prof["tree_avg_us"], "error_games": st["error_games"]})
+    eng.close()
+
+    # configs[3]: Blokus 20x20 four players, 2048 games x 400 sims per search, the tower as evaluator
+    G, budget, searches = 2048, 400, 2
+    dev = capi.Blokus(G, device=device, seed=3)
+    dev.search_config(max_budget=budget)
+    dev.playout(9)
+    dev.sync()
+    tower = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1, device=device)
+    tower.load_weights(synth.make_blob(20, 5, Cs, 0, c_out=91, value_dim=4))
+    dev.search_tower(tower, 8)
+    dev.sync()
+    tower.profile_enable(max(1, searches * (budget + 2) * 2 * (len(Cs) - 1) // 3600))
+    t0 = time.perf_counter()
+    for _ in range(searches):
+        dev.search_tower(tower, budget)
+    dev.sync()
+    el = time.perf_counter() - t0
+    prof = tower.profile_read()
+    bst = dev.search_stats()
+    rows = G * 441.0                                   # raster rows of a launch (21 x 21 per board)
+    out.append({"config": 3, "workload": "blokus 20x20 4-player, 2048 concurrent games x 400 sims per search, NetConfig-2 tower "
+                                         "(5 planes in, 91 policy channels, 4 values) as evaluator, fp16 operands",
+                "value": G * budget * searches / el, "unit": "sims/s", "seconds": el, "ms_per_round": el / (searches * (budget + 2)) * 1e3,
+                # mean over a block's two convolutions: the first moves 2 + 2 B per activation element through HBM, the
+                # second 2 + 4 + 4 + 2 (16-bit in, fp32 residual in and out, 16-bit copy out)
+                "roofline": roof("az_conv3x3_t256s_kernel (mean of a ResBlock's two convolutions)", 2.0 * 9 * 400 * C * C * G, prof,
+                                 hbm_bytes=rows * C * 8.0),
+                "tree_restarts": bst["restarts"]})
+    dev.close()
+    tower.close()
+
+    # configs[4]: tower only, 20 ResBlocks x 256 channels, 15x15, batch 8192; fp16 operands and the compensated mode
+    N, C4, blocks, B = 15, 256, 20, 8192
+    Cs4 = [C4] * (blocks + 1)
+    boards = torch.from_numpy(synth.random_boards(B, N, seed=0, occupancy=0.3)).cuda(device)
+    pol = torch.empty(B, N * N, dtype=torch.float32, device="cuda:%d" % device)
+    val = torch.empty(B, 2, dtype=torch.float32, device="cuda:%d" % device)
+    torch.cuda.synchronize()
+    blob4 = synth.make_blob(N, 3, Cs4, 0)
+    A = N * N
+    flops_eval = 2.0 * 9 * A * (3 * C4 + 2 * blocks * C4 * C4) + 2.0 * A * C4 * 2 + 2.0 * (64 * A + 128)
+    for prec, name, iters in ((capi.AZ_PREC_FP16, "fp16", 5), (capi.AZ_PREC_FP16X3, "fp16x3", 2)):
+        eng = capi.Engine(N, 5, B, Cs=Cs4, max_budget=1, node_cap=8, precision=prec, device=device)
+        eng.load_weights(blob4)
+        eng.tower_forward_dev(boards.data_ptr(), B, pol.data_ptr(), val.data_ptr())
+        eng.sync()
+        eng.profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            eng.tower_forward_dev(boards.data_ptr(), B, pol.data_ptr(), val.data_ptr())
+        eng.sync()
+        el = (time.perf_counter() - t0) / iters
+        prof = eng.profile_read()
+        e = {"config": 4, "workload": "tower only: 15x15, 20 ResBlocks x 256 ch, leaf batch 8192, %s" % (
+                 "fp16 operands" if name == "fp16" else "AZ_PREC_FP16X3 (hi + lo fp16 operands, reduction over 3x the channels: the parity mode)"),
+             "value": B / el, "unit": "evals/s", "ms_per_forward": el * 1e3, "tower_tflops": flops_eval * B / el / 1e12, "dtype": name}
+        if name == "fp16":
+            e["roofline"] = roof("az_conv3x3_t256s_kernel (mean of a ResBlock's two convolutions)", 2.0 * 9 * A * C4 * C4 * B, prof,
+                                 hbm_bytes=B * 256.0 * C4 * 8.0)
+        else:
+            e["roofline"] = roof("az_conv3x3_t256s_kernel, Cin = 3 x 256 (MFMA work of three convolutions per launch)",
+                                 3 * 2.0 * 9 * A * C4 * C4 * B, prof)
+            e["roofline"]["note"] = "achieved counts the MFMA work issued (three products per weight-activation pair); a third of it is the convolution"
+        out.append(e)
+        eng.close()
+
+    # the headline workload in the parity mode (per-layer kernels, every convolution over 3x the channels)
+    N, G, budget = 15, 512, 800
+    eng = capi.Engine(N, 5, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0, device=device,
+                      precision=capi.AZ_PREC_FP16X3)
+    eng.load_weights(synth.make_blob(N, 3, Cs, 0))
+    eng.selfplay_begin(budget)
+    eng.selfplay_run(200)
+    eng.sync()
+    s0 = eng.stats()["sims_backed_up"]
+    t0 = time.perf_counter()
+    eng.selfplay_run(1600)
+    eng.sync()
+    el = time.perf_counter() - t0
+    out.append({"config": 2, "workload": "the headline workload (gomoku 15x15, 512 games, 800 sims/move) in AZ_PREC_FP16X3, the parity mode",
+                "value": (eng.stats()["sims_backed_up"] - s0) / el, "unit": "sims/s", "seconds": el, "ms_per_round": el / 1600 * 1e3, "dtype": "fp16x3"})
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,7 +199,11 @@ def main():
     ap.add_argument("--budget", type=int, default=800)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["bf16", "fp16"], default="fp16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp16x3"], default="fp16",
+                    help="operand format of the tower's convolutions: fp16 (default, the throughput mode), bf16, or fp16x3 "
+                         "(compensated: hi + lo fp16 operands, fp32-class agreement with the reference network, per-layer kernels)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of BASELINE configs[1], [3], [4] that the default single-GPU run appends as other_configs")
     ap.add_argument("--contexts", type=int, default=1,
                     help="split the GPU's games over this many engine contexts (own stream each) so that one "
                          "context's tree kernel overlaps another's tower")
@@ -129,7 +259,7 @@ def main():
 
     N, K, G, budget = args.board, 5, args.games, args.budget
     Cs = synth.NETCONFIG2
-    prec = capi.AZ_PREC_FP16 if args.precision == "fp16" else capi.AZ_PREC_BF16
+    prec = {"fp16": capi.AZ_PREC_FP16, "bf16": capi.AZ_PREC_BF16, "fp16x3": capi.AZ_PREC_FP16X3}[args.precision]
     NC = args.contexts
     assert G % NC == 0
     engs = [capi.Engine(N, K, G // NC, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
@@ -339,6 +469,14 @@ def main():
         line["two_context_overlap"] = overlap
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, N, K, budget, 16)
+        for e in engs:
+            e.close()
+        engs = []
+        if world == 1 and not args.no_other_configs and args.config is None and (N, G, budget, NC, args.leaves) == (15, 512, 800, 1, 1):
+            try:
+                line["other_configs"] = other_configs(local_rank)
+            except Exception as ex:  # noqa: BLE001  (the headline stands on its own)
+                line["other_configs"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
     for e in engs:
         e.close()

@@ -22,14 +22,14 @@ def main():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--precision", choices=["bf16", "fp16"], default="fp16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp16x3"], default="fp16")
     a = ap.parse_args()
     import torch
     from alphazero_amd import capi, synth
     N, C, B = a.board, a.channels, a.batch
     Cs = [C] * (a.blocks + 1)
     eng = capi.Engine(N, 5, B, Cs=Cs, max_budget=1, node_cap=8,
-                      precision=capi.AZ_PREC_FP16 if a.precision == "fp16" else capi.AZ_PREC_BF16)
+                      precision={"fp16": capi.AZ_PREC_FP16, "bf16": capi.AZ_PREC_BF16, "fp16x3": capi.AZ_PREC_FP16X3}[a.precision])
     eng.load_weights(synth.make_blob(N, 3, Cs, 0))
     boards = torch.from_numpy(synth.random_boards(B, N, seed=0, occupancy=0.3)).cuda()
     pol = torch.empty(B, N * N, dtype=torch.float32, device="cuda")
