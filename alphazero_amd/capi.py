@@ -25,7 +25,7 @@ EXPORTS = [
     "az_tower_forward_static", "az_tower_static_max_batch",
     "az_group_create", "az_group_destroy", "az_group_contexts", "az_group_context", "az_group_load_weights",
     "az_group_selfplay_begin", "az_group_selfplay_run", "az_group_sync", "az_group_replay_drain", "az_group_get_stats",
-    "az_ctx_cells", "az_merge_drain", "az_device_count", "az_get_noise",
+    "az_ctx_cells", "az_ctx_device", "az_merge_drain", "az_device_count", "az_get_noise",
     "az_blokus_create", "az_blokus_destroy", "az_blokus_reset", "az_blokus_step", "az_blokus_legal_mask", "az_blokus_boards",
     "az_blokus_state", "az_blokus_playout", "az_blokus_sync", "az_blokus_stream", "az_blokus_orient", "az_blokus_host_state_size",
     "az_blokus_host_reset", "az_blokus_host_step", "az_blokus_host_legal", "az_blokus_host_info",

@@ -25,6 +25,7 @@
 #define AZ_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[AZ_STATIC_SCRATCH_BYTES];
 static unsigned char* g_scratch_ptr[AZ_MAX_DEVICES];
+static hipStream_t g_scratch_user[AZ_MAX_DEVICES];        // the stream of the last az_tower_forward_static call on the device
 static std::mutex g_scratch_mu;
 
 static thread_local std::string g_err;
@@ -289,6 +290,10 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     if (!c) return AZ_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->cfg.device >= 0 && c->cfg.device < AZ_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (g_scratch_user[c->cfg.device] == c->stream) g_scratch_user[c->cfg.device] = nullptr;
+    }
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -303,6 +308,7 @@ extern "C" int az_device_count(void) {
 }
 extern "C" int az_tower_is_fused(const az_ctx* c) { return c && c->fused ? 1 : 0; }
 extern "C" int az_ctx_cells(const az_ctx* c) { return c ? c->A : 0; }
+extern "C" int az_ctx_device(const az_ctx* c) { return c ? c->cfg.device : -1; }
 extern "C" int az_tower_shape(const az_ctx* c, int* N, int* c_in, int* c_out, int* value_dim, int* max_batch) {
     NEED(c);
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
@@ -528,6 +534,15 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
     if (B < 1 || (size_t)B > maxB)
         return fail(AZ_E_CAPACITY, "batch %d does not fit the static scratch: at most %zu boards of %dx%d with %d channels (%u MiB per GPU)",
                     B, maxB, c->cfg.N, c->cfg.N, c->C_pad, AZ_STATIC_SCRATCH_BYTES >> 20);
+    {   // One array per GPU, whoever calls: work of another context (another stream) that still uses it would be
+        // overwritten.  Calls on one stream are ordered by the stream; a different stream must have drained first.
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        hipStream_t& user = g_scratch_user[c->cfg.device];
+        if (user && user != c->stream && hipStreamQuery(user) == hipErrorNotReady)
+            return fail(AZ_E_STATE, "the static scratch of GPU %d is in use by another context's az_tower_forward_static call that has "
+                                    "not finished (one array per GPU: synchronise that context first)", c->cfg.device);
+        user = c->stream;
+    }
     const size_t row = (size_t)c->C_pad * 2;
     const size_t M = (size_t)B * c->P, M_pad = (M + 255) / 256 * 256, rows = M_pad + 2 * (size_t)c->Gd;
     unsigned char* const img[3] = {base, base + AZ_STATIC_SCRATCH_BYTES / 4, base + AZ_STATIC_SCRATCH_BYTES / 2};

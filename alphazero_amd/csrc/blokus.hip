@@ -90,7 +90,8 @@ struct AzbDev {
     uint16_t*  ring_act;
     float*     ring_p;
     float*     ring_reward;     // [ring_cap][4] by absolute player
-    unsigned long long* sp_counters;    // 0 rows in the ring, 1 rows dropped (ring full), 2 moves played, 3 games finished
+    unsigned long long* sp_counters;    // 0 rows in the ring, 1 rows dropped (ring full), 2 moves played, 3 games finished,
+                                        // 4 moves NOT played because the game's root did not fit its arena
 };
 #define AZB_MAX_MOVES 84                                // 4 players x 21 pieces
 #define AZB_PATH_CAP 88                                 // a game has at most 84 pieces
@@ -642,7 +643,11 @@ extern "C" __global__ void __launch_bounds__(64) azb_selfplay_move_kernel(AzbDev
     AZB_SMEM_DECL;
     __shared__ int s_pick;
     const int g = blockIdx.x, lane = threadIdx.x;
-    if (azb_uni(d.t_status[g]) == AZ_ST_RUN || azb_uni(d.n_nodes[g]) == 0 || azb_uni(d.over[g])) return;
+    if (azb_uni(d.t_status[g]) == AZ_ST_RUN || azb_uni(d.over[g])) return;
+    if (azb_uni(d.n_nodes[g]) == 0) {                                   // the root itself did not fit the arena: no move to play
+        if (lane == 0) atomicAdd(&d.sp_counters[4], 1ull);
+        return;
+    }
     azb_load_table(s_tab);
     azb_load(d, g, s_own, s_used, s_last, s_meta);
     const AzEdge* E = d.edges + (size_t)g * d.edge_cap;
@@ -902,6 +907,13 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
     BNEED(b);
     if (b->d.edges) return bfail(AZ_E_STATE, "the search is already configured");
     if (max_budget < 1) return bfail(AZ_E_ARG, "max_budget must be >= 1");
+    // An arena that cannot hold the root's own block (1 header slot + one slot per legal action: 58 at the opening,
+    // 660+ seen in mid-game positions) truncates every search before its first simulation, and a self-play game
+    // on it would never advance: refuse such a size here (and az_blokus_selfplay_stats reports AZ_E_CAPACITY should a
+    // root wider than the floor ever turn up).
+    if (edge_cap > 0 && edge_cap < 1024 + max_budget)
+        return bfail(AZ_E_ARG, "edge_cap " + std::to_string(edge_cap) + " cannot hold a root and its search: at least " +
+                     std::to_string(1024 + max_budget) + " slots per game (1024 + max_budget), 0 = (max_budget + 2) * 1024");
     BHIP(hipSetDevice(b->device));
     const int G = b->d.G;
     b->d.vl = vl; b->d.c_puct_i = (int)c_puct;                        // Node::ucb takes int (node.hpp:47)
@@ -1024,6 +1036,10 @@ extern "C" int az_blokus_search_tower(az_blokus* b, az_ctx* tower, int budget) {
     if (N != AZB_N || ci != AZB_PLANES || co != AZB_ORIENTS || vd != AZB_PLAYERS)
         return bfail(AZ_E_ARG, "the tower must be 20x20 with c_in 5, c_out 91, value_dim 4");
     if (mb < b->d.G) return bfail(AZ_E_ARG, "the tower context takes batches of " + std::to_string(mb) + ", the search has " + std::to_string(b->d.G) + " games");
+    // the tower's kernels read this handle's leaf planes and write its policy / value buffers in place
+    if (az_ctx_device(tower) != b->device)
+        return bfail(AZ_E_ARG, "the tower lives on GPU " + std::to_string(az_ctx_device(tower)) + ", the Blokus games on GPU " +
+                     std::to_string(b->device) + ": they must share a GPU");
     BHIP(hipSetDevice(b->device));
     if (!b->ev_tree) { BHIP(hipEventCreateWithFlags(&b->ev_tree, hipEventDisableTiming)); BHIP(hipEventCreateWithFlags(&b->ev_eval, hipEventDisableTiming)); }
     hipStream_t ts = (hipStream_t)az_stream(tower);
@@ -1192,12 +1208,14 @@ extern "C" int az_blokus_selfplay_stats(az_blokus* b, int64_t* moves, int64_t* g
     if (!b->d.sp_counters) return bfail(AZ_E_STATE, "az_blokus_selfplay_config has not been called");
     BHIP(hipSetDevice(b->device));
     BHIP(hipStreamSynchronize(b->stream));
-    unsigned long long k[4];
+    unsigned long long k[5];
     BHIP(hipMemcpy(k, b->d.sp_counters, sizeof k, hipMemcpyDeviceToHost));
     if (rows) *rows = (int64_t)k[0];
     if (dropped) *dropped = (int64_t)k[1];
     if (moves) *moves = (int64_t)k[2];
     if (games) *games = (int64_t)k[3];
+    if (k[4]) return bfail(AZ_E_CAPACITY, std::to_string(k[4]) + " moves were not played: a game's root (1 + its legal actions) does not fit the " +
+                           std::to_string(b->d.edge_cap) + "-slot arena (az_blokus_search_config edge_cap)");
     return AZ_OK;
 }
 

@@ -250,6 +250,7 @@ typedef int (*az_drain_fn)(void* src, int cap, uint8_t* cells, uint8_t* to_move,
 int az_merge_drain(int n_src, az_drain_fn fn, void* const* srcs, int A, int cap,
                    uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
 int az_ctx_cells(const az_ctx*);                  /* N*N of the context's board */
+int az_ctx_device(const az_ctx*);                 /* the HIP device ordinal the context lives on (az_config.device) */
 
 /* ---- Blokus: 20x20, four players, 21 polyominoes each (rules stated in alphazero_amd/csrc/az_blokus_rules.h).
  * The reference names a Blokus environment (.gitmodules:7-9) without shipping it and its MCTS cannot drive

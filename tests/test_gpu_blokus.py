@@ -326,6 +326,8 @@ def test_search_survives_an_arena_too_small_for_the_position():
     root, then ends with the simulations it has instead of restarting for ever; self-play carries on."""
     G, budget = 4, 12
     dev = capi.Blokus(G, seed=9)
+    with pytest.raises(capi.AzError, match="cannot hold a root"):
+        dev.search_config(max_budget=budget, edge_cap=600)     # below the floor: a root alone can need more
     dev.search_config(max_budget=budget, edge_cap=1500)
     dev.selfplay_config(ring_rows=G * 84, max_budget=budget)
     dev.selfplay_moves(budget, 40)
