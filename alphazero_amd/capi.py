@@ -25,6 +25,7 @@ EXPORTS = [
     "az_tower_forward_static", "az_tower_static_max_batch",
     "az_group_create", "az_group_destroy", "az_group_contexts", "az_group_context", "az_group_load_weights",
     "az_group_selfplay_begin", "az_group_selfplay_run", "az_group_sync", "az_group_replay_drain", "az_group_get_stats",
+    "az_replay_flip", "az_replay_drain_retired", "az_group_replay_flip", "az_group_replay_drain_retired",
     "az_ctx_cells", "az_ctx_device", "az_merge_drain", "az_device_count", "az_get_noise",
     "az_blokus_create", "az_blokus_destroy", "az_blokus_reset", "az_blokus_step", "az_blokus_legal_mask", "az_blokus_boards",
     "az_blokus_state", "az_blokus_playout", "az_blokus_sync", "az_blokus_stream", "az_blokus_orient", "az_blokus_host_state_size",
@@ -341,6 +342,19 @@ class Engine:
         pol = np.empty((cap, self.A), np.float32)
         rew = np.empty((cap, 2), np.float32)
         n = _chk(load().az_replay_drain(self.h, cap, _ptr(cells), _ptr(tm), _ptr(pol), _ptr(rew)))
+        return cells[:n], tm[:n], pol[:n], rew[:n]
+
+    def replay_flip(self):
+        """retire the ring the launches queued so far append to; later launches append to the other one"""
+        _chk(load().az_replay_flip(self.h))
+
+    def replay_drain_retired(self, cap=1 << 16):
+        """rows of the retired ring, waiting only for the launches queued before the flip"""
+        cells = np.empty((cap, self.A), np.uint8)
+        tm = np.empty(cap, np.uint8)
+        pol = np.empty((cap, self.A), np.float32)
+        rew = np.empty((cap, 2), np.float32)
+        n = _chk(load().az_replay_drain_retired(self.h, cap, _ptr(cells), _ptr(tm), _ptr(pol), _ptr(rew)))
         return cells[:n], tm[:n], pol[:n], rew[:n]
 
     def stats(self):

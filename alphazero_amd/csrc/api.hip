@@ -86,6 +86,10 @@ struct az_ctx {
     int* d_actions = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; int* d_illegal = nullptr;
     uint8_t* d_export = nullptr;                          // [G][3][A] planes or [G][A] mask of az_env_boards / az_env_legal_mask
     unsigned long long* d_stats = nullptr;                // [32] az_get_stats' reduction
+    // the two replay rings: launches append to rings[active] (= d.ring_*); az_replay_flip retires it
+    struct Ring { uint8_t* cells; uint8_t* tomove; float* policy; float* reward; } rings[2] = {};
+    int active = 0;
+    hipEvent_t flip_ev = nullptr;                         // recorded at the flip: every writer of the retired ring is in front of it
     int mode = AZ_MODE_SEARCH;
     bool search_active = false;
     int64_t rounds = 0;
@@ -221,9 +225,14 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
     DA(move_idx, G); DA(avg_len, G); DA(game_count, G); DA(sample_ctr, G); DA(noise_ctr, G);
     DA(row_cells, (size_t)G * A * A); DA(row_tomove, (size_t)G * A); DA(row_policy, (size_t)G * A * A);
     d.ring_cap = std::max(4 * G * A / 2, 4096);
-    DA(ring_cells, (size_t)d.ring_cap * A); DA(ring_tomove, d.ring_cap);
-    DA(ring_policy, (size_t)d.ring_cap * A); DA(ring_reward, 2 * (size_t)d.ring_cap);
-    DA(counters, 16); DA(g_ctr, (size_t)G * AZ_GC_STRIDE); DA(g_hw_nodes, G); DA(g_hw_edges, G);
+    DA(counters, 16);
+    for (int r = 0; r < 2; ++r) {
+        AZCHK(dalloc(c, &c->rings[r].cells, (size_t)d.ring_cap * A)); AZCHK(dalloc(c, &c->rings[r].tomove, (size_t)d.ring_cap));
+        AZCHK(dalloc(c, &c->rings[r].policy, (size_t)d.ring_cap * A)); AZCHK(dalloc(c, &c->rings[r].reward, 2 * (size_t)d.ring_cap));
+    }
+    d.ring_cells = c->rings[0].cells; d.ring_tomove = c->rings[0].tomove; d.ring_policy = c->rings[0].policy; d.ring_reward = c->rings[0].reward;
+    d.ring_ctr = d.counters + 4;
+    HIPCHK(hipEventCreateWithFlags(&c->flip_ev, hipEventDisableTiming)); DA(g_ctr, (size_t)G * AZ_GC_STRIDE); DA(g_hw_nodes, G); DA(g_hw_edges, G);
 #undef DA
     HIPCHK(hipMemset(d.root_hist_len, 0xFF, sizeof(int) * G));      // -1: no tree
     {   // uniform noise default so an unset buffer is still a distribution
@@ -296,6 +305,7 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     }
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->flip_ev) (void)hipEventDestroy(c->flip_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return AZ_OK;
@@ -905,21 +915,20 @@ extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
     return AZ_OK;
 }
 
-extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
-    NEED(c); NEED_GAMES(c);
-    if (cap < 0) return fail(AZ_E_ARG, "cap %d is negative", cap);
-    if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
-    HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+// Rows of ring r (not being appended to by anything that is still running) -> the caller's buffers; what does not
+// fit stays, shifted to the front.  Blocking copies: they do not order against the context's stream.
+static int drain_ring(az_ctx* c, int r, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    const az_ctx::Ring& R = c->rings[r];
+    unsigned long long* ctr = c->d.counters + 4 + 2 * r;
     unsigned long long cnt = 0;
-    HIPCHK(hipMemcpy(&cnt, c->d.counters + 4, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&cnt, ctr, 8, hipMemcpyDeviceToHost));
     const size_t A = c->A;
     const int n = (int)std::min<unsigned long long>(cnt, (unsigned long long)cap);
     if (n > 0) {
-        HIPCHK(hipMemcpy(cells, c->d.ring_cells, (size_t)n * A, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(to_move, c->d.ring_tomove, n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(policy, c->d.ring_policy, (size_t)n * A * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(reward, c->d.ring_reward, (size_t)n * 2 * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cells, R.cells, (size_t)n * A, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(to_move, R.tomove, n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(policy, R.policy, (size_t)n * A * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(reward, R.reward, (size_t)n * 2 * 4, hipMemcpyDeviceToHost));
     }
     if (n > 0 && (unsigned long long)n < cnt) {
         // keep the tail: shift it to the front, n rows at a time from the low end so that the source
@@ -927,15 +936,55 @@ extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_m
         const size_t rest = (size_t)(cnt - n);
         for (size_t off = 0; off < rest; off += (size_t)n) {
             const size_t k = std::min<size_t>((size_t)n, rest - off);
-            HIPCHK(hipMemcpy(c->d.ring_cells + off * A, c->d.ring_cells + (off + n) * A, k * A, hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(c->d.ring_tomove + off, c->d.ring_tomove + off + n, k, hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(c->d.ring_policy + off * A, c->d.ring_policy + (off + n) * A, k * A * 4, hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(c->d.ring_reward + off * 2, c->d.ring_reward + (off + n) * 2, k * 8, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(R.cells + off * A, R.cells + (off + n) * A, k * A, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(R.tomove + off, R.tomove + off + n, k, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(R.policy + off * A, R.policy + (off + n) * A, k * A * 4, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(R.reward + off * 2, R.reward + (off + n) * 2, k * 8, hipMemcpyDeviceToDevice));
         }
     }
     cnt -= n;
-    HIPCHK(hipMemcpy(c->d.counters + 4, &cnt, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctr, &cnt, 8, hipMemcpyHostToDevice));
     return n;
+}
+
+// Everything finished so far, oldest first: waits for the context's stream, then empties the retired ring and
+// the active one.
+extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    NEED(c); NEED_GAMES(c);
+    if (cap < 0) return fail(AZ_E_ARG, "cap %d is negative", cap);
+    if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t A = c->A;
+    const int n0 = drain_ring(c, c->active ^ 1, cap, cells, to_move, policy, reward);
+    if (n0 < 0 || n0 == cap) return n0;
+    const int n1 = drain_ring(c, c->active, cap - n0, cells + (size_t)n0 * A, to_move + n0, policy + (size_t)n0 * A, reward + (size_t)n0 * 2);
+    return n1 < 0 ? n1 : n0 + n1;
+}
+
+// The producer's overlap (generate.cpp:110 hands a finished game's rows over while the next search is already the
+// reference's next statement; here the next MOVE of every game is already queued on the GPU): az_replay_flip retires
+// the ring the launches queued so far append to -- launches queued after it append to the other ring -- and
+// az_replay_drain_retired waits for exactly those earlier launches (an event recorded at the flip, not the whole
+// stream) and hands over the retired ring's rows while the later launches keep the GPU busy.
+extern "C" int az_replay_flip(az_ctx* c) {
+    NEED(c); NEED_GAMES(c);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipEventRecord(c->flip_ev, c->stream));
+    c->active ^= 1;
+    const az_ctx::Ring& R = c->rings[c->active];
+    c->d.ring_cells = R.cells; c->d.ring_tomove = R.tomove; c->d.ring_policy = R.policy; c->d.ring_reward = R.reward;
+    c->d.ring_ctr = c->d.counters + 4 + 2 * c->active;
+    return AZ_OK;
+}
+
+extern "C" int az_replay_drain_retired(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    NEED(c); NEED_GAMES(c);
+    if (cap < 0) return fail(AZ_E_ARG, "cap %d is negative", cap);
+    if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipEventSynchronize(c->flip_ev));                 // never recorded (no flip yet): returns at once, the ring is empty
+    return drain_ring(c, c->active ^ 1, cap, cells, to_move, policy, reward);
 }
 
 extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
@@ -954,7 +1003,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     memset(s, 0, sizeof *s);
     s->saturated = (int64_t)sat;
     s->sims = (int64_t)k[0]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
-    s->replay_rows = (int64_t)k[4]; s->replay_dropped = (int64_t)k[5];
+    s->replay_rows = (int64_t)(k[4] + k[6]); s->replay_dropped = (int64_t)(k[5] + k[7]);
     s->rounds = c->rounds;
     s->evals = (int64_t)k[16]; s->descents = (int64_t)k[17]; s->tree_levels = (int64_t)k[18];
     s->children_scanned = (int64_t)k[19]; s->children_expanded = (int64_t)k[20];

@@ -84,14 +84,15 @@ struct AzTreeDev {
     uint8_t*  row_cells;        // [G][A][A]
     uint8_t*  row_tomove;       // [G][A]
     float*    row_policy;       // [G][A][A]
-    // replay ring
+    // replay ring: the one of the context's two that launches currently append to (az_replay_flip swaps them)
     int       ring_cap;
+    unsigned long long* ring_ctr;       // [0] rows in this ring, [1] rows dropped because it was full (= counters + 4 or + 6)
     uint8_t*  ring_cells;       // [ring_cap][A]
     uint8_t*  ring_tomove;      // [ring_cap]
     float*    ring_policy;      // [ring_cap][A]
     float*    ring_reward;      // [ring_cap][2]
     // counters touched at most once per move: [0] sims of completed searches [2] moves [3] games
-    // [4] ring rows [5] dropped.  Everything counted per round lives per game (no hot shared word):
+    // [4] rows [5] dropped of ring 0, [6] [7] of ring 1.  Everything counted per round lives per game (no hot shared word):
     unsigned long long* counters;
     unsigned long long* g_ctr;          // [G][AZ_GC_STRIDE] per-game tallies (one 64-byte line per game, no shared hot word):
                                         //   AZ_GC_EVALS boards submitted to the evaluator, AZ_GC_DESCENTS descents that stood,

@@ -253,6 +253,23 @@ extern "C" int az_group_replay_drain(az_group* g, int cap, uint8_t* cells, uint8
                           cells, to_move, policy, reward);
 }
 
+static int drain_retired_ctx(void* src, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    return az_replay_drain_retired((az_ctx*)src, cap, cells, to_move, policy, reward);
+}
+
+// The two halves of the overlapped hand-over (az_replay_flip / az_replay_drain_retired) for every context: the flip
+// only records an event and swaps pointers, so the calling thread does it; the drain merges in context order.
+extern "C" int az_group_replay_flip(az_group* g) {
+    if (!g) return gfail(AZ_E_ARG, "null argument");
+    for (az_ctx* c : g->ctxs) { const int r = az_replay_flip(c); if (r != AZ_OK) return r; }
+    return AZ_OK;
+}
+extern "C" int az_group_replay_drain_retired(az_group* g, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward) {
+    if (!g) return gfail(AZ_E_ARG, "null argument");
+    return az_merge_drain((int)g->ctxs.size(), drain_retired_ctx, (void* const*)g->ctxs.data(), az_ctx_cells(g->ctxs[0]), cap,
+                          cells, to_move, policy, reward);
+}
+
 extern "C" int az_group_get_stats(az_group* g, az_stats* out) {
     if (!g || !out) return gfail(AZ_E_ARG, "null argument");
     memset(out, 0, sizeof *out);

@@ -564,10 +564,10 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells) {
     const float r0 = win ? (rt == 0 ? 1.f : -1.f) : 0.f;
     int base = -1;
     if (threadIdx.x == 0) {
-        unsigned long long old = atomicAdd(&d.counters[4], 0ull);
+        unsigned long long old = atomicAdd(&d.ring_ctr[0], 0ull);
         for (;;) {
-            if (old + (unsigned long long)i > (unsigned long long)d.ring_cap) { atomicAdd(&d.counters[5], (unsigned long long)i); break; }
-            const unsigned long long prev = atomicCAS(&d.counters[4], old, old + (unsigned long long)i);
+            if (old + (unsigned long long)i > (unsigned long long)d.ring_cap) { atomicAdd(&d.ring_ctr[1], (unsigned long long)i); break; }
+            const unsigned long long prev = atomicCAS(&d.ring_ctr[0], old, old + (unsigned long long)i);
             if (prev == old) { base = (int)old; break; }
             old = prev;
         }

@@ -45,20 +45,41 @@ int main(int argc, char const* argv[]) {
     agent.begin();
     const auto t0 = std::chrono::steady_clock::now();
     long long rows = 0;
+    auto emit = [&](const az::ByteTensor& board, const az::FloatTensor& policy, const az::FloatTensor& reward) {
+        buffer.temporary_append(board, policy);
+        buffer.send_reward(reward);
+    };
+    // The GPUs never wait for the host: while the rows of move k are expanded into their 8 symmetries and sent,
+    // move k + 1 of every game is already queued.  AZ_NO_OVERLAP=1 keeps the plain order (run, wait, drain) for A/B.
+    const bool overlap = getenv("AZ_NO_OVERLAP") == nullptr;
+    agent.run(iter_budget);                       // about one move per slot
     while (alive) {
-        agent.run(iter_budget);                   // about one move per slot
-        rows += agent.drain([&](const az::ByteTensor& board, const az::FloatTensor& policy, const az::FloatTensor& reward) {
-            buffer.temporary_append(board, policy);
-            buffer.send_reward(reward);
-        });
+        if (overlap) {
+            agent.flip();                         // rows of the rounds queued so far: the retired rings
+            agent.run(iter_budget);               // the next move, queued behind them
+            rows += agent.drain_retired(emit);    // waits for the retired rounds only
+        } else {
+            rows += agent.drain(emit);
+            agent.run(iter_budget);
+        }
         agent.load();                             // agent.load() per game start in the reference (generate.cpp:73)
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (verbosity >= 1) {
-            const az_stats s = agent.stats();
+            const az_stats s = agent.stats();     // (waits for the queued rounds: verbosity 0 is the measured mode)
             std::cout << "Game count: " << s.games << " | moves: " << s.moves << " | sims/s: " << (double)s.sims / el
                       << " | rows sent: " << rows * 8 << std::endl;
         }
         if (max_s && el > atof(max_s)) break;
+    }
+    {   // whole-run rates, one JSON line (AZ_SECONDS runs; the interactive run ends with "press enter")
+        rows += agent.drain(emit);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const az_stats s = agent.stats();
+        std::cout << "{\"generate\": {\"seconds\": " << el << ", \"sims_per_s\": " << (double)s.sims_backed_up / el
+                  << ", \"moves_per_s\": " << (double)s.moves / el << ", \"games\": " << s.games
+                  << ", \"rows_per_s\": " << (double)rows / el << ", \"messages_per_s\": " << (double)rows * 8 / el
+                  << ", \"overlap\": " << (overlap ? "true" : "false") << ", \"gpus\": " << devices.size()
+                  << ", \"games_per_gpu\": " << games << ", \"replay_dropped\": " << s.replay_dropped << "}}" << std::endl;
     }
     alive = false;
     thd.detach();

@@ -90,14 +90,22 @@ public:
     }
     void begin() { check(az_group_selfplay_begin(grp, budget)); }
     void run(int rounds) { check(az_group_selfplay_run(grp, rounds)); }
-    // finished rows of every GPU -> sink(board u8 [3,N,N], policy f32 [1,N,N], reward f32 [2]), GPU-major
-    int drain(const std::function<void(const ByteTensor&, const FloatTensor&, const FloatTensor&)>& sink) {
+    // finished rows of every GPU -> sink(board u8 [3,N,N], policy f32 [1,N,N], reward f32 [2]), GPU-major; waits
+    // for everything queued
+    int drain(const std::function<void(const ByteTensor&, const FloatTensor&, const FloatTensor&)>& sink) { return drain_impl(sink, false); }
+    // The overlapped hand-over: flip() retires the rings that the rounds queued so far append to; drain_retired()
+    // waits for those rounds only and hands their rows to the sink while the rounds queued after the flip run.
+    void flip() { check(az_group_replay_flip(grp)); }
+    int drain_retired(const std::function<void(const ByteTensor&, const FloatTensor&, const FloatTensor&)>& sink) { return drain_impl(sink, true); }
+private:
+    int drain_impl(const std::function<void(const ByteTensor&, const FloatTensor&, const FloatTensor&)>& sink, bool retired) {
         const int N = Env::N, A = N * N, cap = 4096;
         std::vector<uint8_t> cells((size_t)cap * A), tm(cap);
         std::vector<float> pol((size_t)cap * A), rew((size_t)cap * 2);
         int total = 0;
         for (;;) {
-            const int n = az_group_replay_drain(grp, cap, cells.data(), tm.data(), pol.data(), rew.data());
+            const int n = retired ? az_group_replay_drain_retired(grp, cap, cells.data(), tm.data(), pol.data(), rew.data())
+                                  : az_group_replay_drain(grp, cap, cells.data(), tm.data(), pol.data(), rew.data());
             check(n);
             for (int r = 0; r < n; ++r) {
                 ByteTensor board({3, N, N});
@@ -112,6 +120,7 @@ public:
         }
         return total;
     }
+public:
     // counters summed over the contexts of every GPU (high-water marks: maximum)
     az_stats stats() { az_stats t{}; check(az_group_get_stats(grp, &t)); return t; }
     az_ctx* context(int i = 0) const { return az_group_context(grp, i); }

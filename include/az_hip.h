@@ -220,6 +220,14 @@ int az_selfplay_run(az_ctx*, int rounds);
  * [n,N*N], reward f32 [n,2] (replay.hpp:56-60,62-79 before symmetry expansion).
  * Returns the number of rows copied (<= cap) or a negative error. */
 int az_replay_drain(az_ctx*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
+/* The hand-over of finished rows without stopping the GPU (generate.cpp:110-113 while the next searches are already
+ * queued): a context has two rings.  az_replay_flip retires the ring that the launches queued SO FAR append to;
+ * launches queued afterwards append to the other one.  az_replay_drain_retired waits for those earlier launches
+ * only (an event recorded at the flip) and drains the retired ring, same row layout and return value as
+ * az_replay_drain, while the later launches run.  az_replay_drain itself waits for the whole stream and empties
+ * both rings, retired first. */
+int az_replay_flip(az_ctx*);
+int az_replay_drain_retired(az_ctx*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
 int az_get_stats(az_ctx*, az_stats*);
 
 /* generate.cpp:37-123 as ONE process over every GPU of the node (the reference runs one generator process;
@@ -243,6 +251,8 @@ int az_group_selfplay_begin(az_group*, int iter_budget);
 int az_group_selfplay_run(az_group*, int rounds);
 int az_group_sync(az_group*);
 int az_group_replay_drain(az_group*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
+int az_group_replay_flip(az_group*);              /* az_replay_flip on every context */
+int az_group_replay_drain_retired(az_group*, int cap, uint8_t* cells, uint8_t* to_move, float* policy, float* reward);
 int az_group_get_stats(az_group*, az_stats*);
 /* The host-side merge az_group_replay_drain is made of, usable on its own (and without a GPU): sources are
  * drained in order through fn(src, cap_left, row buffers at the next free row) until cap rows are out. */

@@ -255,3 +255,38 @@ def test_device_dirichlet_noise_follows_the_reference_sampler():
     assert d_comp < 0.01
     assert d_max < 0.05
     assert abs(frac_tiny[0] - frac_tiny[1]) < 0.01
+
+
+def test_overlapped_row_hand_over_gives_the_same_rows():
+    """az_replay_flip / az_replay_drain_retired (rows of move k handed over while move k + 1 is already queued)
+    against the plain az_replay_drain on the same seeds: the two engines play the same games, so the rows --
+    compared as sorted sets, finished games of one round land in the ring in no fixed order -- are the same, the
+    retired drain never returns a row of a later flip period, and nothing is lost or duplicated."""
+    N, K, G, budget, moves = 5, 4, 24, 16, 40
+    Cs = [16, 16, 16]
+    blob = synth.make_blob(N, 3, Cs, 3, phead_gain=4.0)
+
+    def rows_key(cells, tm, pol, rew):
+        return sorted((cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm)))
+    a = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=4)
+    b = capi.Engine(N, K, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=4)
+    for e in (a, b):
+        e.load_weights(blob)
+        e.selfplay_begin(budget)
+    plain = []
+    for _ in range(moves):
+        a.selfplay_run(budget)
+        plain += rows_key(*a.replay_drain())
+    over, per_period = [], []
+    b.selfplay_run(budget)
+    for _ in range(moves - 1):
+        b.replay_flip()
+        b.selfplay_run(budget)                             # queued behind the retired rounds
+        got = rows_key(*b.replay_drain_retired())
+        per_period.append(len(got))
+        over += got
+    over += rows_key(*b.replay_drain())                    # the rest: both rings, after the stream has drained
+    assert len(plain) > 100 and sorted(plain) == sorted(over)
+    assert sum(per_period) > 0 and b.stats()["replay_rows"] == 0 and b.stats()["replay_dropped"] == 0
+    sa, sb = a.stats(), b.stats()
+    assert (sa["games"], sa["moves"], sa["sims"]) == (sb["games"], sb["moves"], sb["sims"])
