@@ -21,7 +21,7 @@ AZ_OK, AZ_E_ARG, AZ_E_HIP, AZ_E_CAPACITY, AZ_E_STATE, AZ_E_NOWEIGHTS = 0, -1, -2
 EXPORTS = [
     "az_last_error", "az_ctx_create", "az_ctx_destroy", "az_sync", "az_stream", "az_weights_size",
     "az_load_weights", "az_load_weights_dev", "az_weights_info_get", "az_env_reset", "az_env_step", "az_env_boards",
-    "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_set_noise",
+    "az_env_legal_mask", "az_env_set", "az_env_load", "az_tower_forward", "az_tower_forward_dev", "az_tower_forward_masked_dev", "az_set_noise",
     "az_tower_forward_static", "az_tower_static_max_batch",
     "az_group_create", "az_group_destroy", "az_group_contexts", "az_group_context", "az_group_load_weights",
     "az_group_selfplay_begin", "az_group_selfplay_run", "az_group_sync", "az_group_replay_drain", "az_group_get_stats",
@@ -36,7 +36,7 @@ EXPORTS = [
     "az_blokus_noise_device", "az_blokus_selfplay_config", "az_blokus_selfplay_moves", "az_blokus_replay_drain", "az_blokus_selfplay_stats",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
     "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_replay_drain",
-    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
+    "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_profile_overhead", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
 ]
 
 
@@ -127,6 +127,7 @@ def load():
         L.az_load_weights_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.az_tower_forward_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.az_tower_forward_static.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.az_tower_forward_masked_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.az_tower_static_max_batch.restype = C.c_size_t
         L.az_tower_static_max_batch.argtypes = [C.c_void_p]
         L.az_blokus_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int]
@@ -211,6 +212,11 @@ class Engine:
 
     def tower_forward_dev(self, boards_ptr, B, policy_ptr, value_ptr):
         _chk(load().az_tower_forward_dev(self.h, C.c_void_p(boards_ptr), B, C.c_void_p(policy_ptr), C.c_void_p(value_ptr)))
+
+    def tower_forward_masked_dev(self, boards_ptr, B, policy_ptr, value_ptr, wanted_ptr):
+        """only the policy entries whose bit is set in wanted u32 [B, c_out * N] are written"""
+        _chk(load().az_tower_forward_masked_dev(self.h, C.c_void_p(boards_ptr), B, C.c_void_p(policy_ptr), C.c_void_p(value_ptr),
+                                                C.c_void_p(wanted_ptr)))
 
     def tower_forward_static(self, boards_ptr, B, policy_ptr, value_ptr):
         """az_tower_forward_dev without any allocation: activations in the library's per-GPU static array."""
@@ -378,7 +384,10 @@ class Engine:
         ca, ta = C.c_double(), C.c_double()
         cn, tn = C.c_int64(), C.c_int64()
         _chk(load().az_profile_read(self.h, C.byref(ca), C.byref(cn), C.byref(ta), C.byref(tn)))
-        return dict(conv_avg_us=ca.value, conv_launches=cn.value, tree_avg_us=ta.value, tree_launches=tn.value)
+        ov, on = C.c_double(), C.c_int64()
+        _chk(load().az_profile_overhead(self.h, C.byref(ov), C.byref(on)))
+        return dict(conv_avg_us=ca.value, conv_launches=cn.value, tree_avg_us=ta.value, tree_launches=tn.value,
+                    empty_span_us=ov.value, empty_spans=on.value)
 
 
 def host_env_step(N, K, cells, to_move, action):

@@ -98,7 +98,9 @@ struct az_ctx {
     int64_t prof_calls = 0;
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
-    std::vector<std::pair<size_t, int>> prof_spans;       // (first event index, kind 0 conv / 1 tree)
+    std::vector<std::pair<size_t, int>> prof_spans;       // (first event index, kind 0 conv / 1 tree / 2 empty)
+    double prof_empty_us = 0.0;                           // mean empty span of the last az_profile_read
+    int64_t prof_empty_n = 0;
 };
 
 static bool prof_begin(az_ctx* c, int kind, bool sampled, hipStream_t s) {
@@ -432,7 +434,7 @@ extern "C" int az_weights_info_get(const az_ctx* c, az_weights_info* out) {
 // block's second convolution updates in place and the heads read; unused by the fused kernel, whose
 // activations never leave LDS and registers.
 static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev,
-                        unsigned short* actX, unsigned short* actH, float* actR, bool sampled) {
+                        unsigned short* actX, unsigned short* actH, float* actR, bool sampled, const unsigned* mask = nullptr) {
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled, c->stream);
@@ -466,7 +468,7 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
             prof_end(c, on, c->stream);
             az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
         }
-        az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat);
+        az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat, mask);
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
@@ -480,16 +482,16 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1, 0);
         prof_end(c, on, c->stream);
     }
-    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat);
+    az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat, mask);
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }
 
-static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev) {
+static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev, const unsigned* mask = nullptr) {
     if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
     if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
-    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, c->actR, sampled);
+    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, c->actR, sampled, mask);
 }
 
 extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
@@ -497,6 +499,16 @@ extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B,
     if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
     HIPCHK(hipSetDevice(c->cfg.device));
     return tower_run(c, boards_dev, B, policy_dev, value_dev);
+}
+
+// The evaluator as the search needs it: only the policy entries a leaf's expansion will read.  The fused kernel
+// (c_out = 1) writes its N * N entries in any case.
+extern "C" int az_tower_forward_masked_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev,
+                                           const uint32_t* wanted_dev) {
+    NEED(c); NEED(boards_dev); NEED(policy_dev); NEED(value_dev); NEED(wanted_dev);
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER) return fail(AZ_E_STATE, "context has no tower");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    return tower_run(c, boards_dev, B, policy_dev, value_dev, c->fused ? nullptr : (const unsigned*)wanted_dev);
 }
 
 extern "C" int az_tower_forward(az_ctx* c, const uint8_t* boards, int B, float* policy, float* value) {
@@ -909,6 +921,9 @@ extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
         const bool on = prof_begin(c, 1, c->prof_every > 0 && (c->rounds % c->prof_every) == 0, c->stream);
         az_launch_round(c->stream, &c->d, 3, AZ_MODE_SELFPLAY, 0, c->cfg.G);
         prof_end(c, on, c->stream);
+        // an empty span right behind a sampled one: what two event records cost on this stream when nothing lies
+        // between them, i.e. what every span above over-states its kernel by
+        if (on) prof_end(c, prof_begin(c, 2, true, c->stream), c->stream);
         c->rounds++;
     }
     HIPCHK(hipGetLastError());
@@ -1041,8 +1056,8 @@ extern "C" int az_profile_read(az_ctx* c, double* conv_avg_us, int64_t* conv_lau
     NEED(c); NEED(conv_avg_us); NEED(conv_launches); NEED(tree_avg_us); NEED(tree_launches);
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum[2] = {0, 0};
-    int64_t cnt[2] = {0, 0};
+    double sum[3] = {0, 0, 0};
+    int64_t cnt[3] = {0, 0, 0};
     for (auto& sp : c->prof_spans) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->prof_pool[sp.first], c->prof_pool[sp.first + 1]));
@@ -1051,6 +1066,13 @@ extern "C" int az_profile_read(az_ctx* c, double* conv_avg_us, int64_t* conv_lau
     }
     *conv_avg_us = cnt[0] ? sum[0] / cnt[0] : 0.0; *conv_launches = cnt[0];
     *tree_avg_us = cnt[1] ? sum[1] / cnt[1] : 0.0; *tree_launches = cnt[1];
+    c->prof_empty_us = cnt[2] ? sum[2] / cnt[2] : 0.0; c->prof_empty_n = cnt[2];
+    return AZ_OK;
+}
+
+extern "C" int az_profile_overhead(az_ctx* c, double* empty_span_us, int64_t* spans) {
+    NEED(c); NEED(empty_span_us); NEED(spans);
+    *empty_span_us = c->prof_empty_us; *spans = c->prof_empty_n;
     return AZ_OK;
 }
 

@@ -20,7 +20,8 @@ void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const
                            unsigned long long* sat);
 // sat: device counter of work items whose residual stream reached fp16's largest value (az_stats.saturated)
 void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
-                     float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat);
+                     float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat,
+                     const unsigned* mask /* null = every policy entry; else [B][c_out * N] row masks of the entries wanted */);
 // compensated mode: rows [hi | lo | hi] (3 C_pad 16-bit channels) from an fp32 image of `rows` x C_pad values
 void az_launch_cat3(hipStream_t s, int prec, const float* x, unsigned short* cat, size_t rows, int C_pad);
 size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out);     // dynamic LDS of az_heads_kernel / az_stem_kernel (<= 64 KB)

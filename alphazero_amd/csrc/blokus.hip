@@ -1043,6 +1043,7 @@ extern "C" int az_blokus_search_tower(az_blokus* b, az_ctx* tower, int budget) {
     BHIP(hipSetDevice(b->device));
     if (!b->ev_tree) { BHIP(hipEventCreateWithFlags(&b->ev_tree, hipEventDisableTiming)); BHIP(hipEventCreateWithFlags(&b->ev_eval, hipEventDisableTiming)); }
     hipStream_t ts = (hipStream_t)az_stream(tower);
+    const bool dense = getenv("AZ_BLOKUS_DENSE_POLICY") != nullptr;     // A/B: the full [91,20,20] policy per leaf
     AZB_CHK(az_blokus_search_begin(b, budget));
     const int bb = budget > 1 ? budget : 1;
     for (int r = 0, extra = 0;; ++r) {
@@ -1053,7 +1054,9 @@ extern "C" int az_blokus_search_tower(az_blokus* b, az_ctx* tower, int budget) {
         // the tree kernel's leaves -> the tower (its own stream) -> back: two event hand-offs, no host wait
         BHIP(hipEventRecord(b->ev_tree, b->stream));
         BHIP(hipStreamWaitEvent(ts, b->ev_tree, 0));
-        AZB_CHK(az_tower_forward_dev(tower, b->d.leaf_planes, b->d.G, b->d.policy, b->d.value));
+        // (only the priors the expansion will read: the leaf's legal actions, about 300 of the 36 400 entries)
+        if (dense) AZB_CHK(az_tower_forward_dev(tower, b->d.leaf_planes, b->d.G, b->d.policy, b->d.value));
+        else AZB_CHK(az_tower_forward_masked_dev(tower, b->d.leaf_planes, b->d.G, b->d.policy, b->d.value, b->d.leaf_bits));
         BHIP(hipEventRecord(b->ev_eval, ts));
         BHIP(hipStreamWaitEvent(b->stream, b->ev_eval, 0));
     }

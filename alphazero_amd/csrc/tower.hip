@@ -1473,7 +1473,9 @@ template <int PR>
 __global__ void __launch_bounds__(256)
 az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const float* __restrict__ hp,
                 float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd, int c_out, int vd,
-                unsigned long long* __restrict__ sat) {
+                unsigned long long* __restrict__ sat,
+                const unsigned* __restrict__ mask /* null, or per board [c_out * N] row masks: bit x of word co * N + y
+                                                     set = policy entry (co, y, x) is wanted */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int A = N * N, W = N + 1, P = W * W;
     const int MR = (c_out + 1 + 31) / 32 * 32;       // policy channels, then the value channel, padded to MFMA row blocks
@@ -1482,7 +1484,12 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     float* s_u = s_wp + MR * WS;                     // [A]
     float* s_red = s_u + A;                          // [256]
     float* s_f1 = s_red + 256;                       // [64]
+    unsigned* s_mask = (unsigned*)(s_f1 + 64);       // [c_out * N]
     const int b = blockIdx.x, tid = threadIdx.x;
+    // Masked form: the search reads a leaf's policy at its legal actions only (_append_children, mcts.hpp:425-455) --
+    // a few hundred of the c_out * N * N entries when c_out is large -- so only those are written; the softmax's
+    // maximum and sum still run over every logit, and the entries written have the bits of the dense form.
+    if (mask) for (int i = tid; i < c_out * N; i += 256) s_mask[i] = mask[(size_t)b * c_out * N + i];
     const float* wvv = hp + (size_t)c_out * C_pad;
     const float* bp = wvv + C_pad;
     const float bvv = bp[c_out];
@@ -1543,12 +1550,17 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
                 }
                 if (a < A) {
                     float bm = -3.4e38f;
+                    const int ay = a / N, ax = a - ay * N;
 #pragma unroll
                     for (int m = 0; m < 3; ++m)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int co = 32 * (mb0 + m) + 8 * (r >> 2) + 4 * kh + (r & 3);      // C/D layout of the 32x32 MFMAs
-                            if (co < c_out) { acc[m][r] += bp[co]; pol[co * A + a] = acc[m][r]; bm = fmaxf(bm, acc[m][r]); }
+                            if (co < c_out) {
+                                acc[m][r] += bp[co];
+                                if (!mask || (s_mask[co * N + ay] >> ax & 1u)) pol[co * A + a] = acc[m][r];
+                                bm = fmaxf(bm, acc[m][r]);
+                            }
                             else if (co == c_out) s_u[a] = fmaxf(acc[m][r] + bvv, 0.f);
                         }
                     const float nm = fmaxf(run_m, bm);
@@ -1590,7 +1602,18 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
     const float inv = 1.f / s_red[0];
-    for (int i = tid; i < n_pol; i += 256) pol[i] = expf(pol[i] - mx) * inv;
+    if (mask) {
+        for (int w = tid; w < c_out * N; w += 256) {
+            unsigned bits = s_mask[w];
+            const int base = (w / N) * A + (w % N) * N;
+            while (bits) {
+                const int x = __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                pol[base + x] = expf(pol[base + x] - mx) * inv;
+            }
+        }
+    } else
+        for (int i = tid; i < n_pol; i += 256) pol[i] = expf(pol[i] - mx) * inv;
     // value: fc1 with 4 threads per output
     {
         const int o = tid >> 2, part = tid & 3;
@@ -1628,7 +1651,7 @@ extern "C" size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows) {
 }
 
 extern "C" size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out) {
-    return ((size_t)((c_out + 1 + 31) / 32 * 32) * (C_pad + 4) + (size_t)N * N + 256 + 64) * 4;
+    return ((size_t)((c_out + 1 + 31) / 32 * 32) * (C_pad + 4) + (size_t)N * N + 256 + 64 + (size_t)c_out * N) * 4;
 }
 extern "C" size_t az_tower_stem_lds_bytes(int N, int C_pad, int c_in) {
     return (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
@@ -1736,9 +1759,10 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
-                                float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat) {
+                                float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat,
+                                const unsigned* mask) {
     const size_t sm = az_tower_heads_lds_bytes(N, C_pad, c_out);
-    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd, c_out, vd, sat);
+    BY_PREC(az_heads_kernel, dim3(B), dim3(256), sm, s, x, hp, policy, value, N, C_pad, Gd, c_out, vd, sat, mask);
 }
 
 // Compensated mode of the per-layer path (AZ_PREC_FP16X3).  An activation x (fp32) enters a convolution as the pair

@@ -168,6 +168,12 @@ int az_env_load(az_ctx*, const int32_t* hist, const int32_t* hist_len);
  * policy f32 [B,c_out*N*N] (softmax probabilities), value f32 [B,value_dim]. */
 int az_tower_forward(az_ctx*, const uint8_t* boards, int B, float* policy, float* value);
 int az_tower_forward_dev(az_ctx*, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev);
+/* The same forward for a caller that will read only some policy entries -- the search reads a leaf's priors at its
+ * legal actions (_append_children, mcts.hpp:425-455), a few hundred of Blokus' 36 400 -- wanted_dev u32
+ * [B, c_out * N]: bit x of word co * N + y set = entry (co, y, x) is wanted.  Those entries get the bits
+ * az_tower_forward_dev gives them (the softmax still runs over every logit); the others are left untouched. */
+int az_tower_forward_masked_dev(az_ctx*, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev,
+                                const uint32_t* wanted_dev);
 /* PVNetwork's constructor arguments as the context holds them (network.hpp:104): board side, `in`, `out`,
  * value entries, and the largest batch one call takes (any pointer may be NULL) */
 int az_tower_shape(const az_ctx*, int* N, int* c_in, int* c_out, int* value_dim, int* max_batch);
@@ -356,6 +362,9 @@ int az_tower_is_fused(const az_ctx*);
 int az_selfplay_batch(const az_ctx*);
 int az_profile_read(az_ctx*, double* conv_avg_us, int64_t* conv_launches,
                     double* tree_avg_us, int64_t* tree_launches);
+/* What a span over-states its kernel by: the mean duration of the empty spans (two event records with nothing
+ * between them) taken right behind the sampled tree rounds, as of the last az_profile_read. */
+int az_profile_overhead(az_ctx*, double* empty_span_us, int64_t* spans);
 
 /* replay.hpp:80-112: the 8 dihedral variants of one row in emission order,
  * states u8 [8,3,N,N], policies f32 [8,N,N] (host-side helper). */

@@ -413,3 +413,31 @@ def test_blokus_shaped_tower_at_batch_2048_matches_the_reference_fixture():
     polp, valp = eng.tower_forward(planes[perm])
     assert np.array_equal(polp, pol[perm]) and np.array_equal(valp, val[perm])
     assert eng.stats()["saturated"] == 0
+
+
+def test_masked_policy_output_has_the_bits_of_the_dense_one():
+    """az_tower_forward_masked_dev on the Blokus tower's shape: the entries whose bit is set get exactly the values
+    az_tower_forward_dev writes, every other entry of the output buffer is left as it was."""
+    import torch
+    N, B, Cs = 20, 5, synth.NETCONFIG2
+    blob = synth.make_blob(N, 5, Cs, 124, phead_gain=3.0, fc2_gain=3.0, c_out=91, value_dim=4)
+    planes = torch.from_numpy(synth.random_planes(B, 5, N, seed=124)).cuda()
+    eng = capi.Engine(N, 5, B, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    eng.load_weights(blob)
+    dense = torch.empty((B, 91 * 400), dtype=torch.float32, device="cuda")
+    val = torch.empty((B, 4), dtype=torch.float32, device="cuda")
+    sparse = torch.full((B, 91 * 400), -5.0, dtype=torch.float32, device="cuda")
+    val2 = torch.empty((B, 4), dtype=torch.float32, device="cuda")
+    rng = np.random.default_rng(3)
+    want = (rng.random((B, 91, 20, 20)) < 0.01)
+    want[0] = False                                        # a board that wants nothing
+    want[1, 90, 19, 19] = want[1, 0, 0, 0] = True
+    words = (want.astype(np.uint32) << np.arange(20, dtype=np.uint32)).sum(-1).astype(np.uint32)      # [B, 91, 20]
+    wt = torch.from_numpy(words.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    eng.tower_forward_dev(planes.data_ptr(), B, dense.data_ptr(), val.data_ptr())
+    eng.tower_forward_masked_dev(planes.data_ptr(), B, sparse.data_ptr(), val2.data_ptr(), wt.data_ptr())
+    eng.sync()
+    d, s_, m = dense.cpu().numpy(), sparse.cpu().numpy(), want.reshape(B, -1)
+    assert m.sum() > 1000 and np.array_equal(s_[m], d[m]) and (s_[~m] == -5.0).all()
+    assert np.array_equal(val.cpu().numpy(), val2.cpu().numpy())
