@@ -318,6 +318,7 @@ def main():
     run(args.steps * rps)
     barrier()
     el = time.perf_counter() - t0
+    el_local = el
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -332,8 +333,14 @@ def main():
         t = torch.tensor([sims_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         sims_all = int(t.item())
+        # what each rank contributed: its own device counter and its own clock (value = sum / max)
+        mine = torch.tensor([float(sims_local), el_local], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"sims": [int(x[0].item()) for x in allr], "seconds": [float(x[1].item()) for x in allr]}
     else:
         sims_all = sims_local
+        per_rank = None
     if st["error_games"]:
         raise SystemExit("tree arena overflow in %d games" % st["error_games"])
     games_info = None
@@ -469,6 +476,8 @@ def main():
                 "note": "a chain of dependent loads, one per tree level: latency-bound, 512 one-wave blocks"}
         line["consistency"] = {"timed_region_s": el, "rounds_timed": args.steps * rps, "profile_every": every,
                                "sims_per_s_of_full_games_phase": games_info["sims_per_s"] if games_info else None}
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         line["full_games"] = games_info
         line["two_context_overlap"] = overlap
         if world == 1 and not args.no_cpu_baseline:

@@ -1,5 +1,7 @@
 """Edge cases of the search / env entry points on the GPU, each against the oracle's
 restatement of the reference's behaviour (bit-exact) or against the reference's error rule."""
+import os
+
 import numpy as np
 import pytest
 
@@ -290,3 +292,30 @@ def test_overlapped_row_hand_over_gives_the_same_rows():
     assert sum(per_period) > 0 and b.stats()["replay_rows"] == 0 and b.stats()["replay_dropped"] == 0
     sa, sb = a.stats(), b.stats()
     assert (sa["games"], sa["moves"], sa["sims"]) == (sb["games"], sb["moves"], sb["sims"])
+
+
+def test_bench_with_eight_ranks_prints_one_line_that_adds_up():
+    """bench.py as the driver launches it for N = 8 (python -m torch.distributed.run, one rank per GPU), rehearsed on
+    this box with the eight ranks sharing the one GPU and the collectives on gloo (AZ_BENCH_BACKEND): exactly one
+    JSON line comes out, from rank 0; `value` = the sum of the ranks' device-side simulation counters over the
+    slowest rank's time; the single-GPU extras (CPU baseline, other configs) stay out."""
+    import json
+    import subprocess
+    import sys
+    from test_wire import free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AZ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--games", "32", "--budget", "32", "--board", "9", "--full-games", "0", "--no-overlap-probe"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["metric"] == "mcts_simulations_per_sec" and r["scaling"] == "weak" and r["steps"] == 2
+    assert "cpu_baseline" not in r and "other_configs" not in r
+    pr = r["per_rank"]
+    assert len(pr["sims"]) == 8 and all(s == 2 * 32 * 32 for s in pr["sims"])      # every rank: 32 games x 32 sims x 2 moves
+    assert abs(r["value"] - sum(pr["sims"]) / max(pr["seconds"])) < 1e-6 * r["value"]
+    assert abs(r["ms_per_step"] - max(pr["seconds"]) / 2 * 1e3) < 1e-6 * r["ms_per_step"]
