@@ -40,10 +40,11 @@ def test_mcts_pvnetwork_shims_play_a_game(nthreads):
 
 
 @pytest.mark.parametrize("contexts", [1, 2])
-def test_checkpoint_swap_mid_run_goes_through_rccl_and_the_device_fold(contexts):
+def test_checkpoint_swap_mid_run_goes_through_the_group_load_and_the_device_fold(contexts):
     """host/swap_check: ckpt_location.txt rewritten under flock while self-play runs; load() hands the new
-    blob to az_group_load_weights (ncclBroadcast on the group's communicator, BN fold + pack on the GPU) and
-    the network that answers changes; an archive without its .azw twin keeps the current weights."""
+    blob to az_group_load_weights (one host -> device copy, an ncclBroadcast when the group spans more than one
+    GPU, BN fold + pack on the GPU) and the network that answers changes; an archive without its .azw twin keeps
+    the current weights."""
     exe = os.path.join(HOST, "swap_check")
     assert os.path.exists(exe), "build alphazero_amd/host first (__graft_entry__.build())"
     with tempfile.TemporaryDirectory() as d:
