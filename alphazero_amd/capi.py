@@ -30,7 +30,7 @@ EXPORTS = [
     "az_blokus_create", "az_blokus_destroy", "az_blokus_reset", "az_blokus_step", "az_blokus_legal_mask", "az_blokus_boards",
     "az_blokus_state", "az_blokus_playout", "az_blokus_sync", "az_blokus_stream", "az_blokus_orient", "az_blokus_host_state_size",
     "az_blokus_host_reset", "az_blokus_host_step", "az_blokus_host_legal", "az_blokus_host_info",
-    "az_blokus_search_config", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
+    "az_blokus_search_config", "az_blokus_search_reuse", "az_blokus_tree_clear", "az_blokus_selfplay_row_cap", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
     "az_blokus_eval_hash", "az_blokus_eval_io", "az_blokus_search_result", "az_blokus_search_stats",
     "az_blokus_search_tower", "az_tower_shape",
     "az_blokus_noise_device", "az_blokus_selfplay_config", "az_blokus_selfplay_moves", "az_blokus_replay_drain", "az_blokus_selfplay_stats",
@@ -457,9 +457,16 @@ class Blokus:
         _chk(load().az_blokus_playout(self.h, int(steps)))
 
     # -- MCTS ----------------------------------------------------------------
-    def search_config(self, vl=3.0, c_puct=3.0, max_budget=400, edge_cap=0):
+    def search_config(self, vl=3.0, c_puct=3.0, max_budget=400, edge_cap=0, reuse=False):
+        """reuse: keep each game's tree between searches (__make_root + find, mcts.hpp:385-421); self-play then runs
+        the reference's loop in full (warm-up search per game, tree carried from move to move)"""
+        if reuse:
+            _chk(load().az_blokus_search_reuse(self.h, 1))
         _chk(load().az_blokus_search_config(self.h, vl, c_puct, int(max_budget), int(edge_cap)))
-        self.K = int(max_budget)                    # policy entries kept per self-play row
+        self.K = int(max_budget)                    # policy entries kept per self-play row (selfplay_config refreshes it)
+
+    def tree_clear(self):
+        _chk(load().az_blokus_tree_clear(self.h))
 
     def set_noise(self, noise):
         if noise is None:
@@ -507,6 +514,7 @@ class Blokus:
         """after search_config; max_budget, if given, must be the value search_config got"""
         assert max_budget is None or int(max_budget) == getattr(self, "K", None)
         _chk(load().az_blokus_selfplay_config(self.h, int(ring_rows)))
+        self.K = int(load().az_blokus_selfplay_row_cap(self.h))
 
     def selfplay_moves(self, budget, n_moves, tower_engine=None):
         _chk(load().az_blokus_selfplay_moves(self.h, tower_engine.h if tower_engine is not None else None, int(budget), int(n_moves)))

@@ -42,6 +42,7 @@ struct AzbDev {
     uint8_t*  to_move;      // [G]
     uint8_t*  over;         // [G]
     int*      moves;        // [G] pieces placed so far
+    uint16_t* hist;         // [G][84] the actions played since reset: Env::get_id (mcts.hpp:388)
     int*      legal_count;  // [G] legal actions of the player to move (0 once over)
     uint32_t* legal_bits;   // [G][91][20] row masks
     float*    final_reward; // [G][4]
@@ -51,6 +52,16 @@ struct AzbDev {
     int use_noise;
     AzEdge*   edges;        // [G][edge_cap]  a node = one header slot {n = child count, child = player to move} + its child edges
     uint16_t* eact;         // [G][edge_cap]  action of each child edge
+    // tree reuse across searches (__make_root + find, mcts.hpp:385-421), az_blokus_search_reuse:
+    int reuse;              // 1: a search begins by looking the position up in the kept tree
+    AzEdge*   edges1;       // [G][edge_cap]  the second arena: a kept subtree is copied from one to the other, its root to slot 0
+    uint16_t* eact1;
+    int*      arena;        // [G] which arena holds the game's tree
+    int*      root_moves;   // [G] pieces on the board at the tree's root, -1: no tree
+    uint16_t* root_hist;    // [G][84] the root's move history
+    int*      queue;        // [G][q_cap] header slots of the subtree being copied, in BFS order
+    int q_cap;
+    uint8_t*  warm;         // [G] self-play: the game's next search is its warm-up (generate.cpp:77), no move follows it
     int*      n_slots;      // [G] arena slots in use
     int*      n_nodes;      // [G] expanded nodes
     int*      root_n;       // [G]
@@ -74,7 +85,7 @@ struct AzbDev {
     int*      truncated;    // [G] searches ended early because the arena filled up a second time
     unsigned* noise_ctr;    // [G] device-noise draws so far (use_noise == 2)
     // ---- self-play state, allocated by az_blokus_selfplay_config ----
-    int sp_k;               // policy entries kept per row = max_budget (a root child needs a visit to have one)
+    int sp_k;               // policy entries kept per row (a root child needs a visit to have one): max_budget, 4 x with reuse
     int ring_cap;           // rows of the replay ring
     float*     sp_avg_len;      // [G] running mean game length (generate.cpp:25-29,69)
     long long* sp_game_count;   // [G]
@@ -91,7 +102,8 @@ struct AzbDev {
     float*     ring_p;
     float*     ring_reward;     // [ring_cap][4] by absolute player
     unsigned long long* sp_counters;    // 0 rows in the ring, 1 rows dropped (ring full), 2 moves played, 3 games finished,
-                                        // 4 moves NOT played because the game's root did not fit its arena
+                                        // 4 moves NOT played because the game's root did not fit its arena,
+                                        // 5 rows whose policy had more visited children than a row holds (sp_k)
 };
 #define AZB_MAX_MOVES 84                                // 4 players x 21 pieces
 #define AZB_PATH_CAP 88                                 // a game has at most 84 pieces
@@ -252,6 +264,7 @@ __device__ void azb_play(const AzbDev& d, int g, int action, uint32_t* s_own, ui
     if (lane == 0) {
         d.used[g * 4 + p] = s_used[p];
         d.last_piece[g * 4 + p] = (uint8_t)s_last[p];
+        d.hist[(size_t)g * AZB_MAX_MOVES + s_meta[2]] = (uint16_t)action;
         s_meta[2] += 1; d.moves[g] = s_meta[2];
         s_meta[3] = cnt; d.legal_count[g] = cnt;
         if (next >= 0) { s_meta[0] = next; d.to_move[g] = (uint8_t)next; }
@@ -372,7 +385,8 @@ extern "C" __global__ void azb_export_kernel(AzbDev d, uint8_t* planes, uint8_t*
 // and an irregular action set, so a node carries its own child count: a node is a header slot {n = number of
 // children, child = player to move} followed by its child edges in action order; an edge's link is the slot
 // of its child's header (> 0), -1 a stub, -16 - code a terminal leaf whose reward is packed two bits per
-// player in code.  Every search starts from a fresh root.
+// player in code.  A search starts from a fresh root, or -- az_blokus_search_reuse -- from what the kept tree holds
+// for the position (azb_make_root_kernel).
 #define AZB_TERMINAL(code_) (-16 - (code_))
 __device__ __forceinline__ int azb_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -416,13 +430,122 @@ __device__ void azb_device_noise(const AzbDev& d, int g, int count) {
     __syncthreads();
 }
 
+__device__ __forceinline__ AzEdge* azb_E(const AzbDev& d, int g) {
+    return (__builtin_amdgcn_readfirstlane(d.arena[g]) ? d.edges1 : d.edges) + (size_t)g * d.edge_cap;
+}
+__device__ __forceinline__ uint16_t* azb_EA(const AzbDev& d, int g) {
+    return (__builtin_amdgcn_readfirstlane(d.arena[g]) ? d.eact1 : d.eact) + (size_t)g * d.edge_cap;
+}
+
+// root = target (mcts.hpp:417-420): the subtree under the node whose header sits at slot `src` is copied into the
+// other arena in BFS order, its root to slot 0, and becomes the game's tree (the reference drops its shared_ptr to
+// the old root; here the old arena is simply left behind).  A node's place in the new arena is known the moment
+// it is queued -- its header says how many children it has -- so links are rewritten on the fly.  Returns 0 if the
+// subtree has more nodes than the queue holds (the caller then starts from a fresh root).
+__device__ int azb_reroot(const AzbDev& d, int g, int src, int root_n) {
+    const int lane = threadIdx.x;
+    const int ar = __builtin_amdgcn_readfirstlane(d.arena[g]);
+    const AzEdge* E0 = (ar ? d.edges1 : d.edges) + (size_t)g * d.edge_cap;
+    const uint16_t* A0 = (ar ? d.eact1 : d.eact) + (size_t)g * d.edge_cap;
+    AzEdge* E1 = (ar ? d.edges : d.edges1) + (size_t)g * d.edge_cap;
+    uint16_t* A1 = (ar ? d.eact : d.eact1) + (size_t)g * d.edge_cap;
+    int* queue = d.queue + (size_t)g * d.q_cap;
+    if (lane == 0) queue[0] = src;
+    __syncthreads();
+    int new_count = 1, pos = 0;
+    int alloc = 1 + __builtin_amdgcn_readfirstlane(E0[src].n);          // first free slot behind the new root's block
+    bool fits = true;
+    for (int i = 0; i < new_count && fits; ++i) {
+        const int sh = __builtin_amdgcn_readfirstlane(queue[i]);
+        const AzEdge h = E0[sh];
+        const int cnt = __builtin_amdgcn_readfirstlane(h.n);
+        if (lane == 0) { E1[pos] = h; A1[pos] = 0; }
+        for (int c = 0; c < cnt; c += 64) {
+            const int k = c + lane;
+            const bool valid = k < cnt;
+            AzEdge e = {0.f, 0, 0.f, -1};
+            uint16_t act = 0;
+            if (valid) { e = E0[sh + 1 + k]; act = A0[sh + 1 + k]; }
+            const bool has = valid && e.child > 0;
+            int sz = has ? 1 + E0[e.child].n : 0;                       // slots of the child's block
+            const int own = sz;
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(sz, o, 64); if (lane >= o) sz += y; }
+            const unsigned long long m = __ballot(has);
+            if (has) {
+                const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                if (new_count + rank < d.q_cap) queue[new_count + rank] = e.child;
+                e.child = alloc + sz - own;
+            }
+            if (valid) { E1[pos + 1 + k] = e; A1[pos + 1 + k] = act; }
+            new_count += __popcll(m);
+            alloc += __shfl(sz, 63, 64);
+            if (new_count > d.q_cap) fits = false;
+        }
+        pos += 1 + cnt;
+        __syncthreads();
+    }
+    if (!fits) return 0;
+    if (lane == 0) { d.arena[g] = ar ^ 1; d.n_slots[g] = pos; d.n_nodes[g] = new_count; d.root_n[g] = root_n; }
+    __syncthreads();
+    return 1;
+}
+
+// __make_root (mcts.hpp:385-421) for the game's current position, then the search's counters.  find()
+// (node.hpp:83-102) walks the kept tree by the moves played since its root: not found, or found as a child that
+// was never expanded (a Node without state: searching from it is undefined in the reference) -> a fresh root;
+// found below the root -> that subtree becomes the tree, with its statistics and without Dirichlet noise (its
+// parent is not null, mcts.hpp:432); the root itself -> nothing changes, the visits keep accumulating.
+extern "C" __global__ void __launch_bounds__(64) azb_make_root_kernel(AzbDev d, int budget) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (azb_uni(d.over[g])) { if (lane == 0) d.t_status[g] = AZ_ST_IDLE; return; }
+    const int mv = azb_uni(d.moves[g]), rm = azb_uni(d.root_moves[g]);
+    const uint16_t* H = d.hist + (size_t)g * AZB_MAX_MOVES;
+    uint16_t* RH = d.root_hist + (size_t)g * AZB_MAX_MOVES;
+    bool keep = false;
+    if (azb_uni(d.n_nodes[g]) > 0 && rm >= 0 && rm <= mv) {
+        bool mism = false;
+        for (int t = lane; t < rm; t += 64) mism = mism || H[t] != RH[t];                   // node.hpp:89-90
+        if (!__ballot(mism)) {
+            if (rm == mv) keep = true;
+            else {
+                const AzEdge* E = azb_E(d, g);
+                const uint16_t* EA = azb_EA(d, g);
+                int hdr = 0, tn = 0;
+                bool found = true;
+                for (int t = rm; t < mv && found; ++t) {                                    // node.hpp:93-100
+                    const int action = H[t];
+                    const int cnt = azb_uni(E[hdr].n);
+                    int at = -1;
+                    for (int k = lane; k < cnt; k += 64) if (EA[hdr + 1 + k] == action) at = k;
+                    for (int o = 32; o > 0; o >>= 1) at = max(at, __shfl_xor(at, o, 64));
+                    at = azb_uni(at);
+                    if (at < 0) { found = false; break; }
+                    const AzEdge e = E[hdr + 1 + at];
+                    const int child = azb_uni(e.child);
+                    if (child <= 0) { found = false; break; }                               // stub or terminal
+                    hdr = child; tn = azb_uni(e.n);
+                }
+                if (found) keep = azb_reroot(d, g, hdr, tn) != 0;
+            }
+        }
+    }
+    for (int t = lane; t < mv; t += 64) RH[t] = H[t];
+    if (lane == 0) {
+        if (!keep) { d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; }
+        d.root_moves[g] = mv;
+        d.sims_done[g] = 0; d.sims_target[g] = budget > 1 ? budget : 1;
+        d.pending[g] = AZ_PEND_NONE; d.path_len[g] = 0; d.search_restarts[g] = 0;
+        d.t_status[g] = AZ_ST_RUN;
+    }
+}
+
 // Consume the evaluation of the previous round: expand (+ noise at the root) and back up.
 __device__ void azb_tree_apply(const AzbDev& d, int g) {
     const int lane = threadIdx.x;
     const int pend = azb_uni(d.pending[g]);
     if (pend == AZ_PEND_NONE) return;
-    AzEdge* E = d.edges + (size_t)g * d.edge_cap;
-    uint16_t* EA = d.eact + (size_t)g * d.edge_cap;
+    AzEdge* E = azb_E(d, g);
+    uint16_t* EA = azb_EA(d, g);
     const int plen = azb_uni(d.path_len[g]);
     const int* path = d.path + (size_t)g * AZB_PATH_CAP;
     if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
@@ -507,8 +630,8 @@ __device__ void azb_tree_apply(const AzbDev& d, int g) {
 __device__ void azb_tree_select(const AzbDev& d, int g, uint32_t* s_own, uint2* s_rows, const uint2* s_tab,
                                 uint32_t* s_bits, int* s_cnt, uint32_t* s_used, int* s_last, int* s_meta) {
     const int lane = threadIdx.x;
-    AzEdge* E = d.edges + (size_t)g * d.edge_cap;
-    const uint16_t* EA = d.eact + (size_t)g * d.edge_cap;
+    AzEdge* E = azb_E(d, g);
+    const uint16_t* EA = azb_EA(d, g);
     int* path = d.path + (size_t)g * AZB_PATH_CAP;
     uint8_t* owners = d.path_owner + (size_t)g * AZB_PATH_CAP;
     if (azb_uni(d.n_nodes[g]) == 0) {                                   // fresh root: evaluate the root position
@@ -648,10 +771,14 @@ extern "C" __global__ void __launch_bounds__(64) azb_selfplay_move_kernel(AzbDev
         if (lane == 0) atomicAdd(&d.sp_counters[4], 1ull);
         return;
     }
+    if (d.reuse && azb_uni(d.warm[g])) {                                // that was the warm-up search (generate.cpp:77): its
+        if (lane == 0) d.warm[g] = 0;                                   // result is discarded, the tree stays
+        return;
+    }
     azb_load_table(s_tab);
     azb_load(d, g, s_own, s_used, s_last, s_meta);
-    const AzEdge* E = d.edges + (size_t)g * d.edge_cap;
-    const uint16_t* EA = d.eact + (size_t)g * d.edge_cap;
+    const AzEdge* E = azb_E(d, g);
+    const uint16_t* EA = azb_EA(d, g);
     const int cnt = azb_uni(E[0].n);                                    // the root's children: slots 1 .. cnt
     const float rn = (float)azb_uni(d.root_n[g]);
     const int i = s_meta[2] + 1;                                        // generate.cpp:82, 1-based
@@ -670,7 +797,10 @@ extern "C" __global__ void __launch_bounds__(64) azb_selfplay_move_kernel(AzbDev
             if (n > 0 && pos < K) { ra[pos] = EA[1 + k]; rp[pos] = __fdiv_rn((float)n, rn); }     // mcts.hpp:136-146
             base += __popcll(m);
         }
-        if (lane == 0) { d.row_cnt[row] = base < K ? base : K; d.row_tomove[row] = (uint8_t)s_meta[0]; }
+        if (lane == 0) {
+            d.row_cnt[row] = base < K ? base : K; d.row_tomove[row] = (uint8_t)s_meta[0];
+            if (base > K) atomicAdd(&d.sp_counters[5], 1ull);
+        }
     }
     int chosen = -1;
     if ((double)i < (double)d.sp_avg_len[g] * 0.2) {                   // generate.cpp:88: sample ~ visits
@@ -737,6 +867,7 @@ extern "C" __global__ void __launch_bounds__(64) azb_selfplay_move_kernel(AzbDev
         const float al = d.sp_avg_len[g];
         d.sp_avg_len[g] = al + ((float)i - al) / (float)gc;
         atomicAdd(&d.sp_counters[3], 1ull);
+        if (d.reuse) { d.root_moves[g] = -1; d.n_nodes[g] = 0; d.warm[g] = 1; }      // agent.clear() (generate.cpp:113); next: warm-up
     }
     azb_reset_game(d, g, s_own, s_used, s_rows, s_tab, s_bits, s_cnt, true);
 }
@@ -746,6 +877,7 @@ extern "C" __global__ void azb_selfplay_init_kernel(AzbDev d) {
     if (g >= d.G) return;
     d.sp_avg_len[g] = 25.f;                                             // generate.cpp:69
     d.sp_game_count[g] = 0; d.sp_sample_ctr[g] = 0u;
+    if (d.reuse) { d.warm[g] = 1; d.root_moves[g] = -1; d.n_nodes[g] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -819,6 +951,7 @@ extern "C" int az_blokus_create(az_blokus** out, int device, int G, uint64_t see
 #define BA(ptr, n) do { if (rc == AZ_OK) rc = balloc(b, &(ptr), (size_t)(n)); } while (0)
     BA(b->d.own, (size_t)G * 4 * AZB_N); BA(b->d.used, (size_t)G * 4); BA(b->d.last_piece, (size_t)G * 4);
     BA(b->d.to_move, G); BA(b->d.over, G); BA(b->d.moves, G); BA(b->d.legal_count, G);
+    BA(b->d.hist, (size_t)G * AZB_MAX_MOVES);
     BA(b->d.legal_bits, (size_t)G * AZB_SET_WORDS); BA(b->d.final_reward, (size_t)G * 4);
     BA(b->d_actions, G); BA(b->d_reward, (size_t)G * 4); BA(b->d_done, G); BA(b->d_illegal, 4);
     BA(b->d_export, (size_t)G * AZB_ACTIONS);
@@ -911,17 +1044,27 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
     // 660+ seen in mid-game positions) truncates every search before its first simulation, and a self-play game
     // on it would never advance: refuse such a size here (and az_blokus_selfplay_stats reports AZ_E_CAPACITY should a
     // root wider than the floor ever turn up).
+    if (b->d.reuse && max_budget > 16000) return bfail(AZ_E_ARG, "max_budget too large for tree reuse");
     if (edge_cap > 0 && edge_cap < 1024 + max_budget)
         return bfail(AZ_E_ARG, "edge_cap " + std::to_string(edge_cap) + " cannot hold a root and its search: at least " +
                      std::to_string(1024 + max_budget) + " slots per game (1024 + max_budget), 0 = (max_budget + 2) * 1024");
     BHIP(hipSetDevice(b->device));
     const int G = b->d.G;
     b->d.vl = vl; b->d.c_puct_i = (int)c_puct;                        // Node::ucb takes int (node.hpp:47)
-    b->d.edge_cap = edge_cap > 0 ? edge_cap : (max_budget + 2) * 1024;  // ~510 slots per node observed at 2048 games x 400 sims, 660+ at single roots
+    // ~510 slots per node observed at 2048 games x 400 sims, 660+ at single roots; with reuse a tree carries the kept
+    // subtree plus the new search (the first move's: the warm-up's and its own, generate.cpp:77)
+    // (+ 64 nodes: at small budgets the kept subtree is large next to the budget)
+    b->d.edge_cap = edge_cap > 0 ? edge_cap : (b->d.reuse ? 2 * max_budget + 64 : max_budget + 2) * 1024;
     b->max_budget = max_budget;
     int rc = AZ_OK;
 #define BA(ptr, n) do { if (rc == AZ_OK) rc = balloc(b, &(ptr), (size_t)(n)); } while (0)
     BA(b->d.edges, (size_t)G * b->d.edge_cap); BA(b->d.eact, (size_t)G * b->d.edge_cap);
+    BA(b->d.arena, G); BA(b->d.root_moves, G);
+    if (b->d.reuse) {
+        b->d.q_cap = 8 * max_budget + 64;                // nodes of a kept subtree; a larger one is dropped (fresh root)
+        BA(b->d.edges1, (size_t)G * b->d.edge_cap); BA(b->d.eact1, (size_t)G * b->d.edge_cap);
+        BA(b->d.root_hist, (size_t)G * AZB_MAX_MOVES); BA(b->d.queue, (size_t)G * b->d.q_cap); BA(b->d.warm, G);
+    }
     BA(b->d.n_slots, G); BA(b->d.n_nodes, G); BA(b->d.root_n, G); BA(b->d.t_status, G); BA(b->d.sims_done, G); BA(b->d.sims_target, G);
     BA(b->d.pending, G); BA(b->d.path_len, G); BA(b->d.path, (size_t)G * AZB_PATH_CAP); BA(b->d.path_owner, (size_t)G * AZB_PATH_CAP);
     BA(b->d.pend_result, (size_t)G * 4); BA(b->d.leaf_bits, (size_t)G * AZB_SET_WORDS); BA(b->d.leaf_count, G); BA(b->d.leaf_player, G);
@@ -930,7 +1073,29 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
     BA(b->d.search_restarts, G); BA(b->d.truncated, G);
 #undef BA
     if (rc != AZ_OK) { b->d.edges = nullptr; return rc; }
+    BHIP(hipMemset(b->d.root_moves, 0xFF, sizeof(int) * G));         // -1: no tree
     BHIP(hipDeviceSynchronize());            // the zero fills ran on the null stream, the context's stream does not wait for it
+    return AZ_OK;
+}
+
+// Before az_blokus_search_config: keep each game's tree between searches, as the reference's MCTS object does
+// (__make_root + find, mcts.hpp:385-421).  Costs a second arena per game.
+extern "C" int az_blokus_search_reuse(az_blokus* b, int on) {
+    BNEED(b);
+    if (b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_reuse must come before az_blokus_search_config (it sizes the arenas)");
+    b->d.reuse = on ? 1 : 0;
+    return AZ_OK;
+}
+
+// MCTS::clear (mcts.hpp:462-465): drop every game's tree
+extern "C" int az_blokus_tree_clear(az_blokus* b) {
+    BNEED(b);
+    if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
+    BHIP(hipSetDevice(b->device));
+    BHIP(hipMemsetAsync(b->d.root_moves, 0xFF, sizeof(int) * b->d.G, b->stream));
+    BHIP(hipMemsetAsync(b->d.n_nodes, 0, sizeof(int) * b->d.G, b->stream));
+    BHIP(hipMemsetAsync(b->d.n_slots, 0, sizeof(int) * b->d.G, b->stream));
+    BHIP(hipMemsetAsync(b->d.root_n, 0, sizeof(int) * b->d.G, b->stream));
     return AZ_OK;
 }
 
@@ -974,7 +1139,8 @@ extern "C" int az_blokus_search_begin(az_blokus* b, int budget) {
     if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
     if (budget > b->max_budget) return bfail(AZ_E_ARG, "budget exceeds the max_budget given to az_blokus_search_config");
     BHIP(hipSetDevice(b->device));
-    hipLaunchKernelGGL(azb_search_begin_kernel, dim3((b->d.G + 63) / 64), dim3(64), 0, b->stream, b->d, budget);
+    if (b->d.reuse) hipLaunchKernelGGL(azb_make_root_kernel, dim3(b->d.G), dim3(64), 0, b->stream, b->d, budget);
+    else hipLaunchKernelGGL(azb_search_begin_kernel, dim3((b->d.G + 63) / 64), dim3(64), 0, b->stream, b->d, budget);
     BHIP(hipGetLastError());
     return AZ_OK;
 }
@@ -1071,13 +1237,16 @@ extern "C" int az_blokus_search_result(az_blokus* b, int game, int cap, int32_t*
     if (game < 0 || game >= b->d.G) return bfail(AZ_E_ARG, "game out of range");
     BHIP(hipSetDevice(b->device));
     BHIP(hipStreamSynchronize(b->stream));
-    int nn = 0, rn = 0, st = 0;
+    int nn = 0, rn = 0, st = 0, ar = 0;
+    BHIP(hipMemcpy(&ar, b->d.arena + game, 4, hipMemcpyDeviceToHost));
+    const AzEdge* const arena_e = (ar ? b->d.edges1 : b->d.edges) + (size_t)game * b->d.edge_cap;
+    const uint16_t* const arena_a = (ar ? b->d.eact1 : b->d.eact) + (size_t)game * b->d.edge_cap;
     BHIP(hipMemcpy(&nn, b->d.n_nodes + game, 4, hipMemcpyDeviceToHost));
     BHIP(hipMemcpy(&rn, b->d.root_n + game, 4, hipMemcpyDeviceToHost));
     BHIP(hipMemcpy(&st, b->d.t_status + game, 4, hipMemcpyDeviceToHost));
     if (st == AZ_ST_RUN) return bfail(AZ_E_STATE, "the search of this game has not finished");
     AzEdge hdr = {0.f, 0, 0.f, 0};
-    if (nn > 0) BHIP(hipMemcpy(&hdr, b->d.edges + (size_t)game * b->d.edge_cap, sizeof hdr, hipMemcpyDeviceToHost));
+    if (nn > 0) BHIP(hipMemcpy(&hdr, arena_e, sizeof hdr, hipMemcpyDeviceToHost));
     *n_children = nn > 0 ? hdr.n : 0;
     if (root_n) *root_n = rn;
     if (cap == 0) return AZ_OK;
@@ -1086,8 +1255,8 @@ extern "C" int az_blokus_search_result(az_blokus* b, int game, int cap, int32_t*
     std::vector<AzEdge> ed((size_t)*n_children);
     std::vector<uint16_t> ea((size_t)*n_children);
     if (*n_children) {
-        BHIP(hipMemcpy(ed.data(), b->d.edges + (size_t)game * b->d.edge_cap + 1, sizeof(AzEdge) * ed.size(), hipMemcpyDeviceToHost));
-        BHIP(hipMemcpy(ea.data(), b->d.eact + (size_t)game * b->d.edge_cap + 1, 2 * ea.size(), hipMemcpyDeviceToHost));
+        BHIP(hipMemcpy(ed.data(), arena_e + 1, sizeof(AzEdge) * ed.size(), hipMemcpyDeviceToHost));
+        BHIP(hipMemcpy(ea.data(), arena_a + 1, 2 * ea.size(), hipMemcpyDeviceToHost));
     }
     for (size_t i = 0; i < ed.size(); ++i) { actions[i] = ea[i]; n[i] = ed[i].n; v[i] = ed[i].v; p[i] = ed[i].p; }
     return AZ_OK;
@@ -1125,7 +1294,9 @@ extern "C" int az_blokus_selfplay_config(az_blokus* b, int ring_rows) {
     if (b->d.sp_counters) return bfail(AZ_E_STATE, "self-play is already configured");
     if (ring_rows < AZB_MAX_MOVES) return bfail(AZ_E_ARG, "ring_rows must hold at least one game (84 rows)");
     BHIP(hipSetDevice(b->device));
-    const int G = b->d.G, K = b->max_budget;
+    // policy entries per row = visited root children: at most one per simulation ever made below the root -- the
+    // budget from a fresh root; with reuse the kept subtree's too (the first move: 2 x budget, generate.cpp:77)
+    const int G = b->d.G, K = b->d.reuse ? std::min(4 * b->max_budget, 4096) : b->max_budget;
     const size_t rows = (size_t)G * AZB_MAX_MOVES, R = (size_t)ring_rows;
     b->d.sp_k = K; b->d.ring_cap = ring_rows;
     int rc = AZ_OK;
@@ -1211,7 +1382,7 @@ extern "C" int az_blokus_selfplay_stats(az_blokus* b, int64_t* moves, int64_t* g
     if (!b->d.sp_counters) return bfail(AZ_E_STATE, "az_blokus_selfplay_config has not been called");
     BHIP(hipSetDevice(b->device));
     BHIP(hipStreamSynchronize(b->stream));
-    unsigned long long k[5];
+    unsigned long long k[6];
     BHIP(hipMemcpy(k, b->d.sp_counters, sizeof k, hipMemcpyDeviceToHost));
     if (rows) *rows = (int64_t)k[0];
     if (dropped) *dropped = (int64_t)k[1];
@@ -1219,8 +1390,13 @@ extern "C" int az_blokus_selfplay_stats(az_blokus* b, int64_t* moves, int64_t* g
     if (games) *games = (int64_t)k[3];
     if (k[4]) return bfail(AZ_E_CAPACITY, std::to_string(k[4]) + " moves were not played: a game's root (1 + its legal actions) does not fit the " +
                            std::to_string(b->d.edge_cap) + "-slot arena (az_blokus_search_config edge_cap)");
+    if (k[5]) return bfail(AZ_E_CAPACITY, std::to_string(k[5]) + " rows had more visited root children than the " + std::to_string(b->d.sp_k) +
+                           " policy entries a row holds: the rest of their policy was cut off");
     return AZ_OK;
 }
+
+// policy entries a self-play row holds (the K of az_blokus_replay_drain's actions / probs), 0 before az_blokus_selfplay_config
+extern "C" int az_blokus_selfplay_row_cap(const az_blokus* b) { return b ? b->d.sp_k : 0; }
 
 // ------------------------------------------------------------------------- host twin (no GPU needed)
 extern "C" int az_blokus_orient(int o, int* piece, int* h, int* w, int8_t* cells_yx) {

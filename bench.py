@@ -223,7 +223,7 @@ def main():
     if args.config == 1:
         args.board, args.games, args.budget = 9, 256, 400
     elif args.config == 3:
-        sys.argv = [os.path.join(ROOT, "tools", "blokus_search_bench.py"), "--tower", "--selfplay-moves", "3"]
+        sys.argv = [os.path.join(ROOT, "tools", "blokus_search_bench.py"), "--tower", "--selfplay-moves", "3", "--reuse"]
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import blokus_search_bench
         return blokus_search_bench.main()

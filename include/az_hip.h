@@ -296,13 +296,25 @@ void* az_blokus_stream(az_blokus*);
  * reference's search arithmetic on four players and an irregular action set -- an edge is valued for the
  * player who chooses it (result[parent->player], mcts.hpp:336, with four entries), a node carries its own
  * child count, children are in action order, ties go to the first child.  Every search starts from a fresh
- * root; a tree that outgrows its arena (edge_cap slots per game, 0 = (max_budget + 2) * 1024) is dropped and
+ * root unless az_blokus_search_reuse switched the reference's tree reuse on; a tree that outgrows its arena (edge_cap slots per game, 0 = (max_budget + 2) * 1024) is dropped and
  * searched again, and if it outgrows it a second time the search ends with the simulations it has (both counted
  * by az_blokus_search_stats' restarts).  az_blokus_search runs `budget` simulations per game with the integer-hash evaluator
  * (bit-reproducible on the CPU); begin / round / eval_io let an evaluator outside the library take the hash
  * evaluator's place: after a round its input planes are in *planes_dev, before the next round its outputs
  * must be in *policy_dev / *value_dev (softmax over all 91*400 actions, value per player). */
 int az_blokus_search_config(az_blokus*, float vl, float c_puct, int max_budget, int edge_cap);
+/* __make_root + find (mcts.hpp:385-421, node.hpp:83-102), to be called BEFORE az_blokus_search_config (it sizes the
+ * arenas: two per game, default edge_cap (2 * max_budget + 64) * 1024): every search first looks its position up in
+ * the game's kept tree by the moves played since the tree's root.  Found below the root: that subtree becomes the
+ * tree (copied to the other arena, its root to slot 0) with its statistics and no Dirichlet noise; the root itself:
+ * the visits keep accumulating; not found, or a child that was never expanded (undefined in the reference): a
+ * fresh root.  az_blokus_tree_clear is MCTS::clear (mcts.hpp:462-465).  With reuse on, az_blokus_selfplay_moves is the
+ * reference's loop in full: a warm-up search at every game start whose result is discarded (generate.cpp:77; it takes
+ * one of the n_moves steps of that game), the tree carried from move to move, cleared at the game's end
+ * (generate.cpp:113); a row then holds up to az_blokus_selfplay_row_cap() = 4 * max_budget policy entries. */
+int az_blokus_search_reuse(az_blokus*, int on);
+int az_blokus_tree_clear(az_blokus*);
+int az_blokus_selfplay_row_cap(const az_blokus*);
 int az_blokus_set_noise(az_blokus*, const float* noise /* [G,n] or NULL = no noise */, int n);
 int az_blokus_search(az_blokus*, int budget);
 /* the same search with the leaves evaluated by `tower`, a context created with N = 20, c_in = 5, c_out = 91,
@@ -325,8 +337,9 @@ int az_blokus_noise_device(az_blokus*, int on);
  * (generate.cpp:85), the move chosen -- sampled in proportion to the visits while the 1-based move number is below
  * 0.2 x the running mean game length (initially 25), the first arg-max afterwards (generate.cpp:87-100) -- and
  * played; a finished game hands its rows to a ring of `ring_rows` rows with the final reward (generate.cpp:110)
- * and the next game starts in its slot.  Differences from the reference's loop, which cannot run this game: no
- * tree reuse between moves and no warm-up search (every root is fresh), four-entry rewards, and a row's policy is
+ * and the next game starts in its slot.  Differences from the reference's loop, which cannot run this game: tree
+ * reuse between moves and the warm-up search only with az_blokus_search_reuse (else every root is fresh),
+ * four-entry rewards, and a row's policy is
  * kept sparse: entry j < counts[r] says policy[actions[j]] = probs[j] (= n_child / n_root, mcts.hpp:136-146) for
  * the visited root children in action order, every other entry of the [91,20,20] policy being zero. */
 int az_blokus_selfplay_config(az_blokus*, int ring_rows);

@@ -331,19 +331,59 @@ def blokus_search(game, budget, noise=None, vl=3.0, c_puct=3.0):
     return out
 
 
-def blokus_selfplay(n_moves, budget, seed, slot, vl=3.0, c_puct=3.0):
+class BlokusMCTS:
+    """The reference's MCTS object for one Blokus game of the oracle: the tree is kept between searches
+    (__make_root + find, mcts.hpp:385-421), clear() drops it (mcts.hpp:462-465)."""
+
+    def __init__(self, vl=3.0, c_puct=3.0):
+        L = lib()
+        L.azo_blokus_mcts_new.restype = C.c_void_p
+        L.azo_blokus_mcts_new.argtypes = [C.c_float, C.c_float]
+        self.h = C.c_void_p(L.azo_blokus_mcts_new(vl, c_puct))
+
+    def search(self, game, budget, noise=None):
+        k = game.legal()[1]
+        out = dict(actions=np.zeros(k, np.int32), n=np.zeros(k, np.int32), v=np.zeros(k, np.float32), p=np.zeros(k, np.float32))
+        rn, how = C.c_int32(), C.c_int32()
+        nz = None if noise is None else _p(np.ascontiguousarray(noise, np.float32), C.c_float)
+        got = lib().azo_blokus_mcts_search(self.h, game.h, int(budget), nz, _p(out["actions"], C.c_int32), _p(out["n"], C.c_int32),
+                                           _p(out["v"], C.c_float), _p(out["p"], C.c_float), C.byref(rn), C.byref(how))
+        assert got == k, (got, k)
+        out["root_n"], out["reused"] = rn.value, how.value
+        return out
+
+    def clear(self):
+        lib().azo_blokus_mcts_clear(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().azo_blokus_mcts_free(self.h)
+            self.h = None
+
+
+def blokus_selfplay(n_moves, budget, seed, slot, vl=3.0, c_puct=3.0, reuse=False):
     """The move loop of generate.cpp:69-118 on one Blokus game of the oracle, as alphazero_amd/csrc/blokus.hip
-    states it for four players: per move a search of `budget` simulations from a fresh root, the row (planes,
-    to move, policy = n_child / n_root of the visited children in action order) buffered, the move sampled in
-    proportion to the visits while the 1-based move number is below 0.2 x the running mean game length
-    (initially 25; pick = (u * total) >> 32 with u = word 0 of Philox(seed ^ 'SAMP', slot, draws so far)), the first
-    arg-max afterwards; a finished game releases its rows with the final reward and the next game starts.
+    states it for four players: per move a search of `budget` simulations, the row (planes, to move, policy =
+    n_child / n_root of the visited children in action order) buffered, the move sampled in proportion to the
+    visits while the 1-based move number is below 0.2 x the running mean game length (initially 25; pick =
+    (u * total) >> 32 with u = word 0 of Philox(seed ^ 'SAMP', slot, draws so far)), the first arg-max afterwards;
+    a finished game releases its rows with the final reward and the next game starts.
+    reuse = False: every search from a fresh root.  reuse = True: the reference's loop -- one MCTS object whose
+    tree is carried from move to move (mcts.hpp:385-421), a warm-up search at every game start whose result is
+    discarded (generate.cpp:77) and agent.clear() at every game end (generate.cpp:113); the warm-up takes one of
+    the n_moves steps, as it does on the device where the games advance in lockstep.
     Returns (finished rows, moves played, games finished).  Test infrastructure: small cases only."""
     g = Blokus()
+    agent = BlokusMCTS(vl, c_puct) if reuse else None
     avg_len, games, sample_ctr = np.float32(25.0), 0, 0
     rows, pending, moves = [], [], 0
+    warm = reuse
     for _ in range(n_moves):
-        r = blokus_search(g, budget, None, vl, c_puct)
+        if warm:
+            agent.search(g, budget)                     # generate.cpp:77
+            warm = False
+            continue
+        r = agent.search(g, budget) if reuse else blokus_search(g, budget, None, vl, c_puct)
         i = len(pending) + 1
         vis = r["n"] > 0
         pol = (r["n"][vis].astype(np.float32) / np.float32(r["root_n"])).astype(np.float32)
@@ -365,4 +405,7 @@ def blokus_selfplay(n_moves, budget, seed, slot, vl=3.0, c_puct=3.0):
             games += 1
             avg_len = np.float32(avg_len + (np.float32(i) - avg_len) / np.float32(games))
             g.reset()
+            if reuse:
+                agent.clear()                           # generate.cpp:113
+                warm = True
     return rows, moves, games

@@ -96,6 +96,7 @@ struct Game {
     int to_move;
     bool over;
     int moves;
+    int hist[NP * NPIECES];                             /* the actions played since reset: Env::get_id (mcts.hpp:388) */
 };
 
 void reset(Game& g) {
@@ -155,6 +156,7 @@ int step(Game& g, int action, float reward[NP]) {
     for (const Cell& c : o.cells) g.board[y0 + c.first][x0 + c.second] = p;
     g.used[p][o.piece] = true;
     g.last_piece[p] = o.piece;
+    g.hist[g.moves] = action;
     g.moves++;
     for (int k = 1; k <= NP; ++k) {
         const int q = (p + k) % NP;
@@ -241,7 +243,8 @@ int azo_blokus_random_move(void* h, uint64_t seed, uint32_t stream, uint32_t cou
  * leaves storing the env reward (mcts.hpp:266-269), exactly `budget` simulations, output = child n / root n.
  * What the reference leaves to Env and this states: value = result[player to move at the parent] with a
  * four-entry result (mcts.hpp:336 indexes a two-entry one), children in action-index order, ties to the first
- * child (the rule the m,n,k search uses too).  Each search starts from a fresh root (no tree reuse yet).
+ * child (the rule the m,n,k search uses too).  azo_blokus_search starts from a fresh root; the Mcts object below
+ * keeps its tree between searches as the reference's does (__make_root + find, mcts.hpp:385-421, node.hpp:83-102).
  * PARITY UNPINNED like the environment itself: the reference cannot run this game. */
 namespace {
 
@@ -391,6 +394,74 @@ int azo_blokus_search(void* h, int budget, float vl, float c_puct, const float* 
     for (TNode* c : s.root->kids) { actions[k] = c->action; n[k] = c->n; v[k] = c->v; p[k] = c->p; ++k; }
     *root_n = s.root_n;
     if (n_nodes) *n_nodes = s.evals;
+    return k;
+}
+
+/* ---- the search object of the reference's generate loop: one tree kept across searches ----------------------
+ * MCTS::search_probs begins with __make_root(state) (mcts.hpp:121,385-421): find() walks the kept tree by the
+ * state's move history (node.hpp:83-102).  Not found (or no tree): a fresh root, evaluated, n = 1, Dirichlet mix.
+ * Found below the root: that child becomes the root with its statistics, the rest of the tree is dropped, no noise
+ * (its parent is not null, mcts.hpp:432).  Found == the root itself: nothing changes and the visits keep
+ * accumulating -- which is what makes generate.cpp:77's warm-up search double the first move's visits.  Where the
+ * reference is undefined (the state is a child that was never expanded: a Node without state, mcts.hpp:417-420 then
+ * :214) this takes a fresh root, the rule of the m,n,k search. */
+struct Mcts {
+    Search s;
+    std::vector<int> root_hist;
+    bool have = false;
+};
+
+void* azo_blokus_mcts_new(float vl, float c_puct) {
+    Mcts* m = new Mcts;
+    m->s.vl = vl; m->s.c_puct_i = (int)c_puct;
+    return m;
+}
+void azo_blokus_mcts_free(void* h) { delete (Mcts*)h; }
+void azo_blokus_mcts_clear(void* h) {                                      /* MCTS::clear (mcts.hpp:462-465) */
+    Mcts* m = (Mcts*)h;
+    delete m->s.root; m->s.root = nullptr; m->s.root_n = 0; m->have = false; m->root_hist.clear();
+}
+/* outputs as azo_blokus_search; *reused: 0 fresh root, 1 a kept subtree became the root, 2 the root was kept */
+int azo_blokus_mcts_search(void* h, void* game, int budget, const float* noise,
+                           int32_t* actions, int32_t* n, float* v, float* p, int32_t* root_n, int32_t* reused) {
+    Mcts* m = (Mcts*)h;
+    Game& g = *(Game*)game;
+    if (g.over) return -1;
+    Search& s = m->s;
+    int how = 0;
+    if (m->have && (int)m->root_hist.size() <= g.moves &&
+        std::equal(m->root_hist.begin(), m->root_hist.end(), g.hist)) {                   /* node.hpp:86-90 */
+        TNode* t = s.root;
+        TNode* parent = nullptr;
+        for (int i = (int)m->root_hist.size(); i < g.moves && t; ++i) {                    /* node.hpp:93-100 */
+            TNode* next = nullptr;
+            if (t->expanded) for (TNode* c : t->kids) if (c->action == g.hist[i]) { next = c; break; }
+            parent = t; t = next;
+        }
+        if (t && t == s.root) how = 2;
+        else if (t && t->expanded) {                    /* root = target (mcts.hpp:417-420); everything else is dropped */
+            for (TNode*& c : parent->kids) if (c == t) c = nullptr;
+            delete s.root;
+            s.root = t; s.root_n = t->n;
+            how = 1;
+        }
+    }
+    if (how == 0) {
+        delete s.root;
+        s.root = new TNode;
+        float value[NP];
+        expand(s, s.root, g, noise, value);
+        s.root_n = 1;                                                                      /* mcts.hpp:412-413 */
+    }
+    s.root_state = g;
+    m->have = true;
+    m->root_hist.assign(g.hist, g.hist + g.moves);
+    const int b = budget > 1 ? budget : 1;
+    for (int i = 0; i < b; ++i) simulate(s);
+    int k = 0;
+    for (TNode* c : s.root->kids) { actions[k] = c->action; n[k] = c->n; v[k] = c->v; p[k] = c->p; ++k; }
+    *root_n = s.root_n;
+    if (reused) *reused = how;
     return k;
 }
 

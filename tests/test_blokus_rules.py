@@ -244,3 +244,30 @@ def any_move_exists(board, p, used):
                          for y, x in sq for dy, dx in ((1, 1), (1, -1), (-1, 1), (-1, -1))):
                     return True
     return False
+
+
+def test_oracle_search_object_keeps_its_tree_like_the_reference():
+    """azo.BlokusMCTS restates __make_root + find (mcts.hpp:385-421) for the Blokus Env: a first search equals the
+    fresh-root search; a second search of the same position keeps accumulating on the root (what generate.cpp:77's
+    warm-up does to the first move: n = 1 + 2 b); after a move the kept child's visits carry over; clear() drops
+    the tree."""
+    budget = 30
+    g = azo.Blokus()
+    for mv in range(7):
+        g.random_move(8, 0, mv)
+    m = azo.BlokusMCTS()
+    a, b = azo.blokus_search(g, budget), m.search(g, budget)
+    assert b["reused"] == 0 and all(np.array_equal(a[k], b[k]) for k in ("actions", "n", "v", "p")) and b["root_n"] == budget + 1
+    c = m.search(g, budget)
+    assert c["reused"] == 2 and c["root_n"] == 2 * budget + 1 and int(c["n"].sum()) == 2 * budget
+    k = int(np.argmax(c["n"]))
+    kept = int(c["n"][k])
+    g.step(int(c["actions"][k]))
+    d = m.search(g, budget)
+    assert d["reused"] == 1 and d["root_n"] == kept + budget and int(d["n"].sum()) == kept + budget - 1
+    assert (d["p"] > 0).all()                              # priors of the kept node: the evaluator's, no noise mixed in
+    m.clear()
+    e = m.search(g, budget)
+    assert e["reused"] == 0 and e["root_n"] == budget + 1
+    f = azo.blokus_search(g, budget)
+    assert all(np.array_equal(e[k], f[k]) for k in ("actions", "n", "v", "p"))

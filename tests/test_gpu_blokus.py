@@ -252,6 +252,117 @@ def test_config3_search_2048_games_400_sims_with_the_tower():
     assert tower.stats()["saturated"] == 0
 
 
+def test_tree_reuse_across_searches_matches_the_oracle():
+    """az_blokus_search_reuse = the reference's __make_root + find (mcts.hpp:385-421): a second search of the same
+    position keeps accumulating on its root; after a move the subtree under the move played becomes the tree, with
+    its statistics; a move that leads to a never-expanded child, or two moves at once that leave the tree, give a
+    fresh root; az_blokus_tree_clear drops everything.  Root statistics against the oracle's search object, game by
+    game, bit for bit."""
+    G, budget = 6, 40
+    dev = capi.Blokus(G, seed=31)
+    dev.search_config(max_budget=budget, reuse=True)
+    dev.playout(5)
+    dev.sync()
+    ref, agents = [], []
+    for g in range(G):
+        o = azo.Blokus()
+        for mv in range(5):
+            o.random_move(31, g, mv)
+        ref.append(o)
+        agents.append(azo.BlokusMCTS())
+
+    def check(tag, want_reused=None):
+        for g in range(G):
+            if ref[g].over:
+                continue
+            want = agents[g].search(ref[g], budget)
+            got = dev.search_result(g)
+            assert got["root_n"] == want["root_n"], (tag, g, got["root_n"], want["root_n"], want["reused"])
+            for k in ("actions", "n", "v", "p"):
+                assert np.array_equal(got[k], want[k]), (tag, g, k)
+            if want_reused is not None:
+                assert want["reused"] == want_reused[g] if isinstance(want_reused, list) else want["reused"] == want_reused, (tag, g, want["reused"])
+    dev.search(budget)
+    check("fresh", 0)
+    dev.search(budget)                                    # target == root: accumulates (2 x budget + 1)
+    check("same root", 2)
+    # play: game 0..3 the most visited child (expanded: reused), game 4 the LEAST visited legal child (a stub with
+    # n = 0 exists at 40 sims over ~300 children: fresh root), game 5 stays where it is
+    acts = np.full(G, -1, np.int32)
+    how = []
+    for g in range(G):
+        r = dev.search_result(g)
+        if g < 4:
+            k = int(np.argmax(r["n"]))
+        elif g == 4:
+            k = int(np.argmin(r["n"]))
+            assert r["n"][k] == 0
+        else:
+            how.append(2)
+            continue
+        acts[g] = r["actions"][k]
+        ref[g].step(int(acts[g]))
+        how.append(1 if g < 4 else 0)
+    dev.step(acts)
+    dev.search(budget)
+    check("after a move", how)
+    # two more moves straight away on game 0 (the second one leaves what was searched: most likely a stub)
+    for _ in range(2):
+        acts = np.full(G, -1, np.int32)
+        r = dev.search_result(0)
+        acts[0] = r["actions"][int(np.argmax(r["n"]))]
+        ref[0].step(int(acts[0]))
+        dev.step(acts)
+        acts[0] = -1
+        m, _c = dev.legal_mask()
+        acts[0] = int(np.flatnonzero(m[0])[-1])            # the last legal action: rarely visited
+        ref[0].step(int(acts[0]))
+        dev.step(acts)
+        dev.search(budget)
+        check("two plies on")
+    dev.tree_clear()
+    for a in agents:
+        a.clear()
+    dev.search(budget)
+    check("after clear", 0)
+    assert dev.search_stats()["restarts"] == 0
+
+
+def test_selfplay_with_tree_reuse_and_warm_up_matches_the_oracle_loop():
+    """The reference's generate loop in full for Blokus (az_blokus_search_reuse): a warm-up search at every game
+    start (generate.cpp:77), the tree carried from move to move, cleared when the game ends (generate.cpp:113).
+    3 games x 100 steps with the hash evaluator: every finished row equals the oracle's loop, game by game."""
+    G, budget, n_steps, seed = 3, 6, 100, 12
+    dev = capi.Blokus(G, seed=seed)
+    dev.search_config(max_budget=budget, reuse=True)
+    dev.selfplay_config(ring_rows=G * 2 * 84, max_budget=budget)
+    assert dev.K == 4 * budget
+    dev.selfplay_moves(budget, n_steps)
+    st = dev.selfplay_stats()
+    got = dev.replay_drain(G * 2 * 84)
+    assert st["dropped"] == 0
+
+    def dev_row(r):
+        c = got["counts"][r]
+        return (got["planes"][r].tobytes(), int(got["to_move"][r]), got["actions"][r, :c].tobytes(), got["probs"][r, :c].tobytes(),
+                got["reward"][r].tobytes())
+    dev_games = sorted(_game_blocks(got["planes"], dev_row))
+    ref_games, ref_moves, ref_finished = [], 0, 0
+    for g in range(G):
+        rows, moves, games = azo.blokus_selfplay(n_steps, budget, seed, g, reuse=True)
+        ref_moves += moves
+        ref_finished += games
+        ref_games += _game_blocks([r["planes"] for r in rows],
+                                  lambda r, rows=rows: (rows[r]["planes"].tobytes(), int(rows[r]["to_move"]), rows[r]["actions"].astype(np.int32).tobytes(),
+                                                        rows[r]["probs"].tobytes(), rows[r]["reward"].tobytes()))
+    assert st["moves"] == ref_moves and st["games"] == ref_finished and ref_finished >= 3
+    assert dev.search_stats()["restarts"] == 0            # (a tree that outgrew its arena would have restarted: the oracle has no arena)
+    assert dev_games == sorted(ref_games)
+    # the first row of every game comes from a root searched twice: its policy sums to 2 b / (2 b + 1)
+    first = got["planes"][:, :4].reshape(len(got["counts"]), -1).sum(1) == 0
+    assert first.sum() == st["games"] and np.allclose(got["probs"][first].sum(1), 2 * budget / (2 * budget + 1.0), atol=1e-6)
+
+
 def _game_blocks(rows_planes, per_row):
     """split rows (oldest first, each game's rows contiguous) into games at the empty-board rows"""
     blocks, cur = [], []

@@ -23,10 +23,13 @@ def main():
     ap.add_argument("--selfplay-moves", type=int, default=0,
                     help="afterwards play this many self-play moves of every game (search from a fresh root + move, Dirichlet "
                          "noise drawn on the device, finished games restart in place) and report them under \"selfplay\"")
+    ap.add_argument("--reuse", action="store_true",
+                    help="the reference's loop in full: the tree is carried from move to move (__make_root + find, mcts.hpp:385-421) and "
+                         "every game starts with a warm-up search (generate.cpp:77)")
     a = ap.parse_args()
     from alphazero_amd import capi, synth
     dev = capi.Blokus(a.games, seed=3)
-    dev.search_config(max_budget=a.budget)
+    dev.search_config(max_budget=a.budget, reuse=a.reuse)
     dev.playout(a.pieces)
     dev.sync()
     tower = None
@@ -50,7 +53,7 @@ def main():
         dev.reset()
         dev.noise_device(True)
         dev.selfplay_config(ring_rows=a.games * 84, max_budget=a.budget)
-        dev.selfplay_moves(a.budget, 1, tower_engine=tower)          # warm-up move
+        dev.selfplay_moves(a.budget, 2 if a.reuse else 1, tower_engine=tower)          # warm-up (with reuse: the games' warm-up searches, then a move)
         dev.sync()
         t1 = time.perf_counter()
         dev.selfplay_moves(a.budget, a.selfplay_moves, tower_engine=tower)
@@ -60,7 +63,8 @@ def main():
         selfplay = {"moves_per_s": a.games * a.selfplay_moves / el2, "sims_per_s": a.games * a.selfplay_moves * a.budget / el2,
                     "seconds": el2, "moves_timed": a.games * a.selfplay_moves, "games_finished": sp["games"], "rows_in_ring": sp["rows"],
                     "rows_dropped": sp["dropped"], "tree": dev.search_stats(),
-                    "note": "from the empty board: one search of %d simulations from a fresh root per move, device Dirichlet noise" % a.budget}
+                    "note": ("from the empty board: the tree carried from move to move, %d simulations per move, device Dirichlet noise at fresh roots" if a.reuse else
+                             "from the empty board: one search of %d simulations from a fresh root per move, device Dirichlet noise") % a.budget}
     print(json.dumps({"metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
                       "config": {"workload": "blokus 20x20 4-player, %d concurrent games x %d sims per search, %s" % (
                                      a.games, a.budget, "NetConfig-2 tower (stem + 9 ResBlocks x 128 ch, 5 planes in, 91 policy channels, 4 values), "
