@@ -146,8 +146,10 @@ az_stem_mfma_kernel(const uint8_t* __restrict__ planes, unsigned short* __restri
     typedef __attribute__((ext_vector_type(16))) float f32x16s;
     constexpr int KW = CIN * 9, T = (KW + 1) / 2;
     const int A = N * N, W = N + 1, P = W * W;
-    uint8_t* s_in = smem;                            // [CIN][A]
+    float* s_bs = (float*)smem;                      // [C_pad]: the biases (read per position block; a trip to memory each otherwise)
+    uint8_t* s_in = smem + C_pad * 4;                // [CIN][A]
     const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < C_pad; i += 256) s_bs[i] = bias[i];
     for (int i = tid; i < CIN * A; i += 256) s_in[i] = planes[(size_t)b * CIN * A + i];
     __syncthreads();
     const int lane = tid & 63, wvi = tid >> 6, l31 = lane & 31, kh = lane >> 5;
@@ -194,7 +196,7 @@ az_stem_mfma_kernel(const uint8_t* __restrict__ planes, unsigned short* __restri
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 bq = *(const float4*)(bias + c0 + 32 * m + 8 * q + 4 * kh);
+                        const float4 bq = *(const float4*)(s_bs + c0 + 32 * m + 8 * q + 4 * kh);
                         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (cell) o = make_float4(fmaxf(acc[m][4 * q] + bq.x, 0.f), fmaxf(acc[m][4 * q + 1] + bq.y, 0.f),
                                                   fmaxf(acc[m][4 * q + 2] + bq.z, 0.f), fmaxf(acc[m][4 * q + 3] + bq.w, 0.f));
@@ -1463,14 +1465,35 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 }
 
 // ------------------------------------------------------------------- heads
+#ifdef AZ_TOWER_TIMING
+__device__ unsigned long long az_heads_ts[32];       // 100 MHz stamps of thread 0 of block 0 at the phase boundaries
+#define HSTAMP(slot_) do { if (blockIdx.x == 0 && threadIdx.x == 0) az_heads_ts[slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int az_heads_timing_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(az_heads_ts), sizeof(unsigned long long) * 32);
+}
+#else
+#define HSTAMP(slot_) do {} while (0)
+#endif
 // One block per board.  PolicyHead (network.hpp:51-60): 1x1 conv to c_out channels -> softmax over the
 // c_out*N*N entries (layout [c_out][N][N] = get_action_shape()).  ValueHead (network.hpp:75-83): 1x1 conv ->
 // BN(1) -> ReLU -> fc1 (N*N -> 64) -> ReLU -> fc2 (64 -> vd) -> softmax*2-1 (vd = 2 in the reference; a game
 // with more players asks for one entry per player).
 // hp layout (fp32): wp[c_out][C_pad], wv[C_pad], bp[c_out], bv (BN folded into wv/bv), then
-// fc1w [64][A], fc1b [64], fc2w [vd][64], fc2b [vd].
+// fc1 transposed [A][64], fc1b [64], fc2w [vd][64], fc2b [vd].
+//
+// Both 1x1 convolutions are one fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation):
+// rows = output channels (policy, then value) in blocks of 32, columns = 32 cells of the board, K = C_pad.  The
+// work splits into units of (32 cells) x (32 output channels); a wave takes every fourth unit, consecutive units
+// being the row blocks of one cell block (the four waves read the same activations at about the same time).
+// Lane l carries cell l & 31 and the k half kh = l >> 5; MFMA step t of a 128-channel slab pairs kh with channel
+// 64 kh + t, so a lane's 64 activations of a slab are one contiguous 256-byte run of its cell's fp32 row
+// (16 x 16-byte loads) and its weights four consecutive floats of one LDS row per read.  The activations of the
+// next (unit, slab) are loaded into a second register set before the MFMAs of this one issue.  The accumulators
+// start at the biases.  The softmax's maximum and sum are kept as this lane's running (max, sum of 2^((logit -
+// max) log2 e)) over the logits it produces; the logits cross the output buffer once (written here, rescaled in
+// place below with the exact exponential).
 template <int PR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const float* __restrict__ hp,
                 float* __restrict__ policy, float* __restrict__ value, int N, int C_pad, int Gd, int c_out, int vd,
                 unsigned long long* __restrict__ sat,
@@ -1481,154 +1504,254 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     const int MR = (c_out + 1 + 31) / 32 * 32;       // policy channels, then the value channel, padded to MFMA row blocks
     const int WS = C_pad + 4;                        // row stride of the weight image: ds_read_b128 of 32 rows without bank conflicts
     float* s_wp = (float*)smem;                      // [MR][WS]
-    float* s_u = s_wp + MR * WS;                     // [A]
-    float* s_red = s_u + A;                          // [256]
-    float* s_f1 = s_red + 256;                       // [64]
-    unsigned* s_mask = (unsigned*)(s_f1 + 64);       // [c_out * N]
+    float* s_bias = s_wp + MR * WS;                  // [MR]: policy biases, the value bias, zeros
+    unsigned* s_mask = (unsigned*)(s_bias + MR);     // [N][MR]: the board's masks with the channel index innermost, zeros past c_out
+    float* s_u = (float*)(s_mask + N * MR);          // [A]
+    float* s_red = s_u + A;                          // [264]
+    float* s_f1 = s_red + 264;                       // [64]
     const int b = blockIdx.x, tid = threadIdx.x;
     // Masked form: the search reads a leaf's policy at its legal actions only (_append_children, mcts.hpp:425-455) --
     // a few hundred of the c_out * N * N entries when c_out is large -- so only those are written; the softmax's
     // maximum and sum still run over every logit, and the entries written have the bits of the dense form.
-    if (mask) for (int i = tid; i < c_out * N; i += 256) s_mask[i] = mask[(size_t)b * c_out * N + i];
     const float* wvv = hp + (size_t)c_out * C_pad;
     const float* bp = wvv + C_pad;
-    const float bvv = bp[c_out];
-    const float* fc1w = bp + c_out + 1;
-    const float* fc1b = fc1w + 64 * A;
+    const float* fc1t = bp + c_out + 1;
+    const float* fc1b = fc1t + 64 * A;
     const float* fc2w = fc1b + 64;
     const float* fc2b = fc2w + 64 * vd;
     float* pol = policy + (size_t)b * c_out * A;
-    for (int i = tid; i < MR * (C_pad / 4); i += 256) {          // wp rows and the wv row are contiguous in hp
-        const int r = i / (C_pad / 4), c4 = i % (C_pad / 4);
-        *(float4*)(s_wp + r * WS + 4 * c4) = r <= c_out ? *(const float4*)(hp + (size_t)r * C_pad + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef float f32x4h __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(16))) float f32x16h;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    const int lane = tid & 63, wvi = tid >> 6, l31h = lane & 31, kh = lane >> 5;
+    const int n_mb = MR / 32, n_units = (A + 31) / 32 * n_mb, n_slab = C_pad / 128;
+    // the 256-byte run of (unit u, slab sl) this lane multiplies
+#define HEADS_XROW(u_, sl_) (x + ((size_t)(Gd + b * P + (min((u_) / n_mb * 32 + l31h, A - 1) / N) * W + min((u_) / n_mb * 32 + l31h, A - 1) % N)) * C_pad + (sl_) * 128 + kh * 64)
+#define HEADS_XLOAD(dst_, u_, sl_) do { const float* row_ = HEADS_XROW(u_, sl_); _Pragma("unroll") for (int q = 0; q < 16; ++q) dst_[q] = *(const f32x4h*)(row_ + 4 * q); } while (0)
+    // (an empty statement that reads the sixteen registers: the wait for their loads lands here, not in front of the MFMAs)
+#define HEADS_XWAIT(r_) asm volatile("" :: "v"(r_[0]), "v"(r_[1]), "v"(r_[2]), "v"(r_[3]), "v"(r_[4]), "v"(r_[5]), "v"(r_[6]), "v"(r_[7]), \
+                                     "v"(r_[8]), "v"(r_[9]), "v"(r_[10]), "v"(r_[11]), "v"(r_[12]), "v"(r_[13]), "v"(r_[14]), "v"(r_[15]))
+    f32x4h xa[16], xb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xa[q] = xb[q] = (f32x4h){0.f, 0.f, 0.f, 0.f};
+    HSTAMP(0);
+    if (wvi < n_units) HEADS_XLOAD(xa, wvi, 0);                  // the first unit's activations travel under the staging below
+    // staging, every load of a group issued before the first write to LDS (one trip to memory per group, not one per row)
+    if (mask) {
+        for (int i = tid; i < (MR - c_out) * N; i += 256) s_mask[(i % N) * MR + c_out + i / N] = 0u;
+        for (int i0 = tid; i0 < c_out * N; i0 += 8 * 256) {
+            unsigned mw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mw[k] = i0 + 256 * k < c_out * N ? mask[(size_t)b * c_out * N + i0 + 256 * k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + 256 * k; if (i < c_out * N) s_mask[(i % N) * MR + i / N] = mw[k]; }
+        }
     }
+    for (int i = tid; i < MR; i += 256) s_bias[i] = i <= c_out ? bp[i] : 0.f;          // bp[c_out] is the value bias
+    if (tid == 0) s_f1[0] = 0.f;                                 // saturation flag until the value head needs the array
+    for (int i0 = tid; i0 < MR * (C_pad / 4); i0 += 12 * 256) {  // wp rows and the wv row are contiguous in hp
+        float4 wr[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int i = i0 + 256 * k, r = i / (C_pad / 4), c4 = i % (C_pad / 4);
+            wr[k] = r <= c_out ? *(const float4*)(hp + (size_t)r * C_pad + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int i = i0 + 256 * k, r = i / (C_pad / 4), c4 = i % (C_pad / 4);
+            if (i < MR * (C_pad / 4)) *(float4*)(s_wp + r * WS + 4 * c4) = wr[k];
+        }
+    }
+    HEADS_XWAIT(xa);                                             // (unconditional: a wait behind a branch is invisible to the next branch)
     __syncthreads();
+    HSTAMP(1);
 
-    // Both 1x1 convolutions as one fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation):
-    // rows = output channels (policy, then value), columns = 32 cells of the board, K = C_pad.  A wave takes
-    // every fourth block of 32 cells.  Lane l carries cell l & 31 and the k half kh = l >> 5; MFMA step t of
-    // a 128-channel slab pairs kh with channel 64 kh + t, so a lane's 64 activations are one contiguous 256-byte
-    // run of its cell's fp32 row (16 x 16-byte loads, held in registers across the row blocks) and its weights
-    // four consecutive floats of one LDS row per read.  The logits pass through the output buffer.
-    // The softmax's maximum and sum are kept as this lane's running (max, sum of exp(logit - max)) over the logits it
-    // produces: the logits then cross the output buffer once (written here, rescaled in place below).
     float run_m = -3.4e38f, run_s = 0.f;
     float xmax = 0.f;                                // largest value of the stream this lane read (fp16: saturation check)
     {
-        typedef __attribute__((ext_vector_type(16))) float f32x16h;
-        const int lane = tid & 63, wvi = tid >> 6, l31h = lane & 31, kh = lane >> 5;
-        for (int cb = wvi; cb * 32 < A; cb += 4) {
+        int u = wvi, sl = 0;
+        f32x16h acc;
+        unsigned want = 0u;
+        // one (unit, slab) step: xc holds its activations (arrived), xn receives the next step's
+        auto step = [&](f32x4h (&xc)[16], f32x4h (&xn)[16]) {
+            int un = u, sn = sl + 1;
+            if (sn == n_slab) { sn = 0; un = u + 4; }
+            const bool more = un < n_units;
+            if (more) HEADS_XLOAD(xn, un, sn);
+            const int cb = u / n_mb, mb = u - cb * n_mb;
             const int a = cb * 32 + l31h, ac = min(a, A - 1);
-            const float* row = x + ((size_t)(Gd + b * P + (ac / N) * W + ac % N)) * C_pad + kh * 64;
-            for (int mb0 = 0; mb0 < MR / 32; mb0 += 3) {
-                f32x16h acc[3];
+            if (sl == 0) {
+                HSTAMP(2 + 3 * min(u >> 2, 5));
+                // accumulators start at the biases; this lane's outputs are channels 32 mb + 8 j + 4 kh + i
+                // (C/D layout of the 32x32 MFMAs), j, i = 0..3: register 4 j + i
+                want = mask ? 0u : 0xffffu;
+                const int ay = ac / N, ax = ac - ay * N;
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-                for (int ch0 = 0; ch0 < C_pad; ch0 += 128) {
-                    float4 xr[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) xr[q] = *(const float4*)(row + ch0 + 4 * q);
-                    if (PR == 1 && mb0 == 0) {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) xmax = fmaxf(fmaxf(xmax, fmaxf(xr[q].x, xr[q].y)), fmaxf(xr[q].z, xr[q].w));
+                for (int j = 0; j < 4; ++j) {
+                    const float4 b4 = *(const float4*)(s_bias + 32 * mb + 8 * j + 4 * kh);
+                    acc[4 * j] = b4.x; acc[4 * j + 1] = b4.y; acc[4 * j + 2] = b4.z; acc[4 * j + 3] = b4.w;
+                    if (mask) {
+                        const uint4 m4 = *(const uint4*)(s_mask + ay * MR + 32 * mb + 8 * j + 4 * kh);
+                        want |= ((m4.x >> ax & 1u) | (m4.y >> ax & 1u) << 1 | (m4.z >> ax & 1u) << 2 | (m4.w >> ax & 1u) << 3) << (4 * j);
                     }
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        if (mb0 + m >= MR / 32) continue;
-                        const float* wrow = s_wp + (32 * (mb0 + m) + l31h) * WS + ch0 + kh * 64;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float4 w4 = *(const float4*)(wrow + 4 * q);
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, xr[q].x, acc[m], 0, 0, 0);
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, xr[q].y, acc[m], 0, 0, 0);
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, xr[q].z, acc[m], 0, 0, 0);
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, xr[q].w, acc[m], 0, 0, 0);
-                        }
-                    }
-                }
-                if (a < A) {
-                    float bm = -3.4e38f;
-                    const int ay = a / N, ax = a - ay * N;
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int co = 32 * (mb0 + m) + 8 * (r >> 2) + 4 * kh + (r & 3);      // C/D layout of the 32x32 MFMAs
-                            if (co < c_out) {
-                                acc[m][r] += bp[co];
-                                if (!mask || (s_mask[co * N + ay] >> ax & 1u)) pol[co * A + a] = acc[m][r];
-                                bm = fmaxf(bm, acc[m][r]);
-                            }
-                            else if (co == c_out) s_u[a] = fmaxf(acc[m][r] + bvv, 0.f);
-                        }
-                    const float nm = fmaxf(run_m, bm);
-                    float bs = 0.f;
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int co = 32 * (mb0 + m) + 8 * (r >> 2) + 4 * kh + (r & 3);
-                            if (co < c_out) bs += expf(acc[m][r] - nm);
-                        }
-                    run_s = run_s * expf(run_m - nm) + bs;
-                    run_m = nm;
                 }
             }
+            if (PR == 1 && mb == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xmax = fmaxf(fmaxf(xmax, fmaxf(xc[q].x, xc[q].y)), fmaxf(xc[q].z, xc[q].w));
+            }
+            const float* wrow = s_wp + (32 * mb + l31h) * WS + sl * 128 + kh * 64;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 w4 = *(const float4*)(wrow + 4 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, xc[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, xc[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, xc[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, xc[q].w, acc, 0, 0, 0);
+            }
+            // the next step's activations have had the MFMAs' time to arrive; waiting here keeps the wait in front of
+            // this unit's stores (loads and stores retire through one in-order counter)
+            HEADS_XWAIT(xn);
+            if (sl == n_slab - 1) {
+                HSTAMP(3 + 3 * min(u >> 2, 5));
+                if (a < A) {
+                    const int co0 = 32 * mb + 4 * kh;                 // register r holds channel co0 + 8 (r >> 2) + (r & 3)
+                    float bm = -3.4e38f, bs = 0.f;
+                    if (32 * mb + 32 <= c_out) {                      // a row block of policy channels only (the same for every lane)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) bm = fmaxf(bm, acc[r]);
+                        if (want) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (want >> r & 1u) pol[(co0 + 8 * (r >> 2) + (r & 3)) * A + a] = acc[r];
+                        }
+                        const float nm = fmaxf(run_m, bm);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) bs += __builtin_amdgcn_exp2f((acc[r] - nm) * LOG2E);
+                        run_s = run_s * __builtin_amdgcn_exp2f((run_m - nm) * LOG2E) + bs;
+                        run_m = nm;
+                    } else {
+                        // the last row block: policy channels, then the value channel, then padding; which of a lane's
+                        // registers are which differs between the two k halves, so selects, not branches
+                        const int rem = c_out - co0;                  // register r is a policy channel iff 8 (r >> 2) + (r & 3) < rem
+                        float uval = 0.f;
+                        unsigned pmask = 0u;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ci = 8 * (r >> 2) + (r & 3);
+                            pmask |= (ci < rem ? 1u : 0u) << r;
+                            bm = ci < rem ? fmaxf(bm, acc[r]) : bm;
+                            uval = ci == rem ? acc[r] : uval;
+                        }
+                        if (rem >= 0 && rem < 32 && !(rem & 4)) s_u[a] = fmaxf(uval, 0.f);
+                        const unsigned wsel = want & pmask;
+                        if (wsel) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (wsel >> r & 1u) pol[(co0 + 8 * (r >> 2) + (r & 3)) * A + a] = acc[r];
+                        }
+                        const float nm = fmaxf(run_m, bm);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float e = __builtin_amdgcn_exp2f((acc[r] - nm) * LOG2E);
+                            bs += 8 * (r >> 2) + (r & 3) < rem ? e : 0.f;
+                        }
+                        run_s = run_s * __builtin_amdgcn_exp2f((run_m - nm) * LOG2E) + bs;
+                        run_m = nm;
+                    }
+                }
+                HSTAMP(4 + 3 * min(u >> 2, 5));
+            }
+            u = un; sl = sn;
+        };
+        while (u < n_units) {
+            step(xa, xb);
+            if (u >= n_units) break;
+            step(xb, xa);
         }
     }
-    __syncthreads();
+#undef HEADS_XROW
+#undef HEADS_XLOAD
+#undef HEADS_XWAIT
+    HSTAMP(25);
     // fp16 operands: a residual stream that reached the format's largest value was clamped on the way (relu_cap in
     // the convolutions' epilogues): count the board, its answer is not the network's (az_stats.saturated)
-    if (PR == 1) {
-        s_red[tid] = xmax;
-        __syncthreads();
-        if (tid == 0) {
-            float m = 0.f;
-            for (int i = 0; i < 256; ++i) m = fmaxf(m, s_red[i]);
-            if (m >= 65504.f) atomicAdd(sat, 1ull);
-        }
-        __syncthreads();
-    }
+    if (PR == 1 && xmax >= 65504.f) s_f1[0] = 1.f;   // every writer stores the same value
     // softmax over the c_out * A entries: combine the lanes' running pairs, then one pass over the logits
     const int n_pol = c_out * A;
-    s_red[tid] = run_m;
+    float wm = run_m;
+    for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+    if (lane == 0) s_red[wvi] = wm;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]); __syncthreads(); }
-    const float mx = s_red[0];
+    HSTAMP(26);
+    if (PR == 1 && tid == 0 && s_f1[0] != 0.f) atomicAdd(sat, 1ull);
+    const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float ws = run_s * expf(run_m - mx);             // a lane without logits: 0 * exp(-huge) = 0
+    for (int o = 32; o > 0; o >>= 1) ws += __shfl_xor(ws, o, 64);
+    if (lane == 0) s_red[4 + wvi] = ws;
     __syncthreads();
-    s_red[tid] = run_s * expf(run_m - mx);           // a lane without logits: 0 * exp(-huge) = 0
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
-    const float inv = 1.f / s_red[0];
+    const float inv = 1.f / ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    HSTAMP(27);
+    // value: fc1 with the weights transposed (a wave reads whole rows of 64 outputs), the cells split four ways;
+    // issued before the softmax pass so that its loads are in flight under it
+    {
+        const int o = tid & 63, part = tid >> 6;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int a = part;
+        for (; a + 12 < A; a += 16) {
+            s0 += fc1t[a * 64 + o] * s_u[a];
+            s1 += fc1t[(a + 4) * 64 + o] * s_u[a + 4];
+            s2 += fc1t[(a + 8) * 64 + o] * s_u[a + 8];
+            s3 += fc1t[(a + 12) * 64 + o] * s_u[a + 12];
+        }
+        for (; a < A; a += 4) s0 += fc1t[a * 64 + o] * s_u[a];
+        s_red[8 + tid] = (s0 + s1) + (s2 + s3);      // (s_red holds 256 + 8 floats)
+    }
+    const float f1b = fc1b[lane];
+    float f2w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f2w[k] = k < vd ? fc2w[k * 64 + lane] : 0.f;
+    HSTAMP(28);
     if (mask) {
-        for (int w = tid; w < c_out * N; w += 256) {
-            unsigned bits = s_mask[w];
-            const int base = (w / N) * A + (w % N) * N;
-            while (bits) {
-                const int x = __ffs((int)bits) - 1;
-                bits &= bits - 1u;
-                pol[base + x] = expf(pol[base + x] - mx) * inv;
+        // each thread's words eight at a time, one wanted entry of every word per round: the rounds' loads are
+        // independent of each other
+        for (int i0 = tid; i0 < N * MR; i0 += 8 * 256) {
+            unsigned wd[8];
+            float* prow[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + 256 * k;
+                wd[k] = i < N * MR ? s_mask[i] : 0u;
+                const int y = i / MR, co = i - y * MR;
+                prow[k] = wd[k] ? pol + co * A + y * N : pol;            // (a word without bits is read at entry 0, and not written)
+            }
+            unsigned any = wd[0] | wd[1] | wd[2] | wd[3] | wd[4] | wd[5] | wd[6] | wd[7];
+            while (any) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = prow[k][wd[k] ? __ffs((int)wd[k]) - 1 : 0];
+                any = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (wd[k]) {
+                        prow[k][__ffs((int)wd[k]) - 1] = expf(v[k] - mx) * inv;
+                        wd[k] &= wd[k] - 1u;
+                        any |= wd[k];
+                    }
             }
         }
     } else
         for (int i = tid; i < n_pol; i += 256) pol[i] = expf(pol[i] - mx) * inv;
-    // value: fc1 with 4 threads per output
-    {
-        const int o = tid >> 2, part = tid & 3;
-        float s = 0.f;
-        for (int a = part; a < A; a += 4) s += fc1w[o * A + a] * s_u[a];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (part == 0) s_f1[o] = fmaxf(s + fc1b[o], 0.f);
-    }
     __syncthreads();
+    HSTAMP(29);
     if (tid < 64) {
+        const float f1 = fmaxf(s_red[8 + tid] + s_red[8 + 64 + tid] + s_red[8 + 128 + tid] + s_red[8 + 192 + tid] + f1b, 0.f);
         float z[8];
         float m2 = -3.4e38f;
-        for (int k = 0; k < vd; ++k) {
-            float zk = fc2w[k * 64 + tid] * s_f1[tid];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= vd) break;
+            float zk = f2w[k] * f1;
             for (int o = 32; o > 0; o >>= 1) zk += __shfl_xor(zk, o, 64);
             z[k] = zk + fc2b[k];
             m2 = fmaxf(m2, z[k]);
@@ -1639,6 +1762,7 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
             for (int k = 0; k < vd; ++k) value[(size_t)vd * b + k] = z[k] / den * 2.f - 1.f;
         }
     }
+    HSTAMP(30);
 }
 
 // ------------------------------------------------------------ host launchers
@@ -1651,7 +1775,7 @@ extern "C" size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows) {
 }
 
 extern "C" size_t az_tower_heads_lds_bytes(int N, int C_pad, int c_out) {
-    return ((size_t)((c_out + 1 + 31) / 32 * 32) * (C_pad + 4) + (size_t)N * N + 256 + 64 + (size_t)c_out * N) * 4;
+    return ((size_t)((c_out + 1 + 31) / 32 * 32) * (C_pad + 5 + N) + (size_t)N * N + 264 + 64) * 4;
 }
 extern "C" size_t az_tower_stem_lds_bytes(int N, int C_pad, int c_in) {
     return (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
@@ -1680,7 +1804,7 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
                                const float* bias, int B, int N, int C_pad, int Gd, int c_in) {
     // the planes the two games here use run on the fp32 MFMA form; any other count on the generic kernel
     if (c_in == 3 || c_in == 5) {
-        const size_t smm = (size_t)c_in * N * N + 16;
+        const size_t smm = (size_t)c_in * N * N + 16 + (size_t)C_pad * 4;
 #define STEM_MFMA(PR_, CIN_) hipLaunchKernelGGL((az_stem_mfma_kernel<PR_, CIN_>), dim3(B), dim3(256), smm, s, planes, out, out32, w, bias, N, C_pad, Gd)
         if (prec == 1) { if (c_in == 3) STEM_MFMA(1, 3); else STEM_MFMA(1, 5); }
         else { if (c_in == 3) STEM_MFMA(0, 3); else STEM_MFMA(0, 5); }

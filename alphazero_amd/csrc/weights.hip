@@ -158,14 +158,16 @@ __global__ void __launch_bounds__(256) az_fold_small_kernel(AzFoldArgs a) {
         for (int e = threadIdx.x; e < 64 * A; e += 256) ht[258 + (size_t)(e % A) * 64 + e / A] = fc1w[e];   // fc1 transposed [A][64]
         for (int e = threadIdx.x; e < tail; e += 256) ht[258 + (size_t)64 * A + e] = fc1w[(size_t)64 * A + e];
     } else {
-        float* hp = a.head_p;                                 // wp[c_out][Cp], wv[Cp], bp[c_out], bv, fc1w [64][A], fc1b, fc2w, fc2b
+        float* hp = a.head_p;                                 // wp[c_out][Cp], wv[Cp], bp[c_out], bv, fc1 [A][64], fc1b, fc2w, fc2b
         for (int e = threadIdx.x; e < a.c_out * C; e += 256) hp[(size_t)(e / C) * Cp + e % C] = pc[e];
         float* wv = hp + (size_t)a.c_out * Cp;
         for (int ch = threadIdx.x; ch < C; ch += 256) wv[ch] = (float)(vc[ch] * vs);
         float* bp = wv + Cp;
         for (int co = threadIdx.x; co < a.c_out; co += 256) bp[co] = pc[(size_t)a.c_out * C + co];
         if (threadIdx.x == 0) bp[a.c_out] = bvf;
-        for (int e = threadIdx.x; e < 64 * A + tail; e += 256) bp[a.c_out + 1 + e] = fc1w[e];
+        float* ft = bp + a.c_out + 1;                             // fc1 transposed [A][64], then fc1b, fc2w, fc2b as they are
+        for (int e = threadIdx.x; e < 64 * A; e += 256) ft[(size_t)(e % A) * 64 + e / A] = fc1w[e];
+        for (int e = threadIdx.x; e < tail; e += 256) ft[(size_t)64 * A + e] = fc1w[(size_t)64 * A + e];
     }
 }
 
