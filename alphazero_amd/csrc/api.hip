@@ -93,6 +93,15 @@ struct az_ctx {
     int mode = AZ_MODE_SEARCH;
     bool search_active = false;
     int64_t rounds = 0;
+    // the persistent pair (az_selfplay_run_pair): the tree kernel's own stream, the events that order it against the
+    // context's stream, the hand-over words, what the launches so far have published
+    hipStream_t stream2 = nullptr;
+    hipEvent_t pair_ev[2] = {nullptr, nullptr};
+    AzPairDev pair = {};
+    unsigned pair_base = 0;
+    int n_cu = 0;
+    int64_t pair_launches = 0, pair_rounds = 0;
+    std::vector<std::pair<size_t, int>> pair_spans;       // (first event index, rounds) of the sampled pair launches
     // HIP-event sampling of the conv / tree kernels on the context's stream
     int prof_every = 0;
     int64_t prof_calls = 0;
@@ -241,6 +250,15 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         std::vector<float> nz((size_t)G * A, 1.0f / (float)A);
         HIPCHK(hipMemcpy(d.noise, nz.data(), nz.size() * 4, hipMemcpyHostToDevice));
     }
+    AZCHK(dalloc(c, &c->pair.plane_seq, S)); AZCHK(dalloc(c, &c->pair.eval_seq, S));
+    AZCHK(dalloc(c, &c->pair.abort, 4)); AZCHK(dalloc(c, &c->pair.busy, G));
+    c->pair.plane_stride = (3 * A + 15) / 16 * 16;
+    AZCHK(dalloc(c, &c->pair.planes_wt, S * (size_t)(c->pair.plane_stride / 4)));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+        c->n_cu = prop.multiProcessorCount;
+    }
     AZCHK(dalloc(c, &c->d_actions, G)); AZCHK(dalloc(c, &c->d_reward, 2 * (size_t)G));
     AZCHK(dalloc(c, &c->d_done, G));
     AZCHK(dalloc(c, &c->d_export, (size_t)G * 3 * A));
@@ -308,6 +326,9 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->flip_ev) (void)hipEventDestroy(c->flip_ev);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (auto& e : c->pair_ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return AZ_OK;
@@ -332,7 +353,8 @@ extern "C" int az_tower_shape(const az_ctx* c, int* N, int* c_in, int* c_out, in
     return AZ_OK;
 }
 extern "C" int az_selfplay_batch(const az_ctx* c) { return c ? c->cfg.G * c->d.L : 0; }
-extern "C" int az_sync(az_ctx* c) { NEED(c); return sync_all(c); }
+static int pair_check(az_ctx* c);
+extern "C" int az_sync(az_ctx* c) { NEED(c); AZCHK(sync_all(c)); return c->tower_only ? AZ_OK : pair_check(c); }
 extern "C" void* az_stream(az_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // ----------------------------------------------------------------- weights
@@ -904,6 +926,9 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     HIPCHK(hipMemsetAsync(c->d.g_hw_nodes, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.g_hw_edges, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.err, 0, sizeof(int) * c->cfg.G, c->stream));
+    HIPCHK(hipMemsetAsync(c->pair.abort, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->pair.busy, 0, sizeof(unsigned long long) * c->cfg.G, c->stream));
+    c->pair_launches = 0; c->pair_rounds = 0;
     az_launch_selfplay_begin(c->stream, &c->d);
     // issue the first evaluation so that every later round is evaluate -> tree
     az_launch_round(c->stream, &c->d, 2, AZ_MODE_SELFPLAY, 0, c->cfg.G);
@@ -912,9 +937,101 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     return AZ_OK;
 }
 
+// Whether the context's self-play rounds can run as the persistent pair: the one-launch tower, one leaf per tree
+// per round, and room for a tree wave on every CU beside the tower's workgroup.
+static const char* pair_unfit(const az_ctx* c) {
+    if (c->cfg.eval_mode != AZ_EVAL_TOWER || !c->fused) return "the tower does not run as one launch per evaluation";
+    if (c->d.L != 1) return "leaves_per_round > 1";
+    if (az_tower_fused_lds_bytes(c->cfg.N, 2 * c->num_res, 256) + 64 + AZ_TREE_SMEM_BYTES > 160 * 1024)
+        return "no LDS left on a CU for a tree wave beside the tower's workgroup";
+    return nullptr;
+}
+
+// A wait of the pair that ran out (the two kernels were not resident together): sticky, reported by every later call.
+static int pair_check(az_ctx* c) {
+    if (!c->pair_launches) return AZ_OK;
+    unsigned ab = 0;
+    HIPCHK(hipMemcpy(&ab, c->pair.abort, 4, hipMemcpyDeviceToHost));
+    if (ab) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out: the two kernels were not "
+                                     "resident together (another process on this GPU, or a profiler that serialises launches); "
+                                     "the games of this context are no longer in step -- run such set-ups with az_selfplay_run");
+    return AZ_OK;
+}
+
+extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
+    NEED(c); NEED_GAMES(c);
+    if (c->mode != AZ_MODE_SELFPLAY) return fail(AZ_E_STATE, "az_selfplay_begin has not been called");
+    if (const char* why = pair_unfit(c)) return fail(AZ_E_STATE, "az_selfplay_run_pair: %s", why);
+    if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
+    if (rounds < 1) return AZ_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        for (auto& e : c->pair_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    AzPairDev pr = c->pair;
+    pr.base = c->pair_base;
+    pr.rounds = rounds;
+    const char* to = getenv("AZ_PAIR_TIMEOUT_MS");
+    const double ms = to ? atof(to) : 4000.0;
+    pr.timeout_ticks = (unsigned)std::min(4.0e9, std::max(1.0, ms) * 1e5);         // 100 MHz ticks
+    // timing experiments (wrong games with bit 0 or 2): 1 = the tower never waits, 2 = no early look at the next tile's
+    // words, 4 = no tree kernel (with 1: the tower alone; without: the tower's first wait runs out, the drain path)
+    const char* dbg_s = getenv("AZ_PAIR_FLAGS");
+    const int dbg = dbg_s ? atoi(dbg_s) : 0;
+    pr.flags = (unsigned)(dbg & 3);
+    // the tree kernel starts behind everything queued on the context's stream, and the stream goes on behind both
+    HIPCHK(hipEventRecord(c->pair_ev[0], c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->pair_ev[0], 0));
+    const bool sampled = c->prof_every > 0 && c->prof_used + 2 <= c->prof_pool.size();
+    if (sampled) { c->pair_spans.push_back({c->prof_used, rounds}); (void)hipEventRecord(c->prof_pool[c->prof_used], c->stream); }
+    // round 1 of the launch evaluates what the last select left in leaf_planes: the tower reads planes_wt only
+    HIPCHK(hipMemcpy2DAsync(c->pair.planes_wt, (size_t)pr.plane_stride, c->d.leaf_planes, (size_t)3 * c->A, (size_t)3 * c->A,
+                            (size_t)c->cfg.G, hipMemcpyDeviceToDevice, c->stream));
+    const int blocks = az_launch_tower_pair(c->stream, c->prec, (const uint8_t*)c->pair.planes_wt, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
+                                            c->head_pt, c->d.policy, c->d.value, c->cfg.G, c->cfg.N, c->Gd, 2 * c->num_res,
+                                            c->d_sat, &pr, c->n_cu);
+    if (blocks <= 0) return fail(AZ_E_STATE, "az_selfplay_run_pair: the persistent tower kernel does not fit");
+    if (sampled) { (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream); c->prof_used += 2; }
+    if (!(dbg & 4)) az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
+    HIPCHK(hipEventRecord(c->pair_ev[1], c->stream2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pair_ev[1], 0));
+    HIPCHK(hipGetLastError());
+    c->pair_base += (unsigned)rounds;
+    c->rounds += rounds;
+    c->pair_launches++; c->pair_rounds += rounds;
+    return AZ_OK;
+}
+
+extern "C" int az_pair_read(az_ctx* c, double* launch_avg_us, int64_t* launches, int64_t* rounds, double* tree_step_avg_us) {
+    NEED(c); NEED_GAMES(c); NEED(launch_avg_us); NEED(launches); NEED(rounds); NEED(tree_step_avg_us);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    AZCHK(pair_check(c));
+    double us = 0.0; int64_t n = 0, r = 0;
+    for (auto& sp : c->pair_spans) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_pool[sp.first], c->prof_pool[sp.first + 1]));
+        us += ms * 1000.0; n++; r += sp.second;
+    }
+    *launch_avg_us = n ? us / n : 0.0; *launches = n; *rounds = r;
+    // ticks (100 MHz) the tree waves worked, waits excluded, over every game-step of every pair launch so far
+    std::vector<unsigned long long> busy(c->cfg.G);
+    HIPCHK(hipMemcpy(busy.data(), c->pair.busy, sizeof(unsigned long long) * c->cfg.G, hipMemcpyDeviceToHost));
+    double ticks = 0.0;
+    for (auto b : busy) ticks += (double)b;
+    const double steps = (double)c->pair_rounds * c->cfg.G;
+    *tree_step_avg_us = steps > 0 ? ticks / steps * 0.01 : 0.0;
+    return AZ_OK;
+}
+
 extern "C" int az_selfplay_run(az_ctx* c, int rounds) {
     NEED(c); NEED_GAMES(c);
     if (c->mode != AZ_MODE_SELFPLAY) return fail(AZ_E_STATE, "az_selfplay_begin has not been called");
+    {   // AZ_PAIR=1: every self-play round of a context that can, as the persistent pair (A/B runs, soak tests)
+        const char* e = getenv("AZ_PAIR");
+        if (e && atoi(e) != 0 && !pair_unfit(c)) return az_selfplay_run_pair(c, rounds);
+    }
     HIPCHK(hipSetDevice(c->cfg.device));
     for (int r = 0; r < rounds; ++r) {
         AZCHK(run_evaluator(c));
@@ -1015,6 +1132,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     }
     HIPCHK(hipMemcpyAsync(&sat, c->d_sat, sizeof sat, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->tower_only) AZCHK(pair_check(c));
     memset(s, 0, sizeof *s);
     s->saturated = (int64_t)sat;
     s->sims = (int64_t)k[0]; s->moves = (int64_t)k[2]; s->games = (int64_t)k[3];
@@ -1040,6 +1158,7 @@ extern "C" int az_profile_enable(az_ctx* c, int every) {
     c->prof_calls = 0;
     c->prof_used = 0;
     c->prof_spans.clear();
+    c->pair_spans.clear();
     if (every > 0 && c->prof_pool.empty()) {
         c->prof_pool.reserve(8192);
         for (int i = 0; i < 8192; ++i) {

@@ -103,6 +103,50 @@ struct AzTreeDev {
     int*      g_hw_edges;       // [G]
 };
 
+// Hand-over words of the persistent pair: az_tower_pair_kernel (one workgroup per CU, its tiles round after round)
+// and az_round_pair_kernel (one tree wave per CU beside it) run a whole batch of rounds in ONE launch each and pass
+// every game's leaf planes / policy + value to each other through memory, game by game, with no grid-wide step:
+//   tree wave, game g, round i : waits eval_seq[g] >= base + i, applies + selects, copies the leaf's planes to
+//                                planes_wt with write-through stores, publishes plane_seq[g] = base + i + 1
+//   tower workgroup, tile t    : waits plane_seq[g] >= base + i for its boards (i = 1: ready before the launch),
+//                                evaluates, publishes eval_seq[g] = base + i
+// A wait that lasts longer than timeout_ticks (the two kernels are not resident together) raises abort[0]; every
+// wave of both kernels then leaves at its next wait, so the grids always drain.
+struct AzPairDev {
+    unsigned* plane_seq;            // [G]
+    unsigned* eval_seq;             // [G]
+    unsigned* planes_wt;            // [G][plane_stride / 4] the planes once more, as whole words stored write-through
+    int       plane_stride;         // bytes per game in planes_wt: 3 A rounded up to 16
+    unsigned* abort;                // [4]
+    unsigned long long* busy;       // [G] 100 MHz ticks the tree wave worked on the game (waits excluded)
+    unsigned  base;                 // evaluations of every game published by earlier launches
+    int       rounds;
+    unsigned  timeout_ticks;        // 100 MHz
+    unsigned  flags;                // timing experiments: bit 0 the tower never waits for planes (wrong games), bit 1 it
+                                    // does not look at its next tile's words ahead of time
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned az_pair_peek(const unsigned* w) {
+    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // bypasses this CU's L1
+}
+// One lane's wait until *w has reached `want` (sequence numbers: compared as a signed difference).
+template <int SLEEP>
+__device__ inline bool az_pair_wait(const unsigned* w, unsigned want, unsigned* abort, unsigned limit) {
+    if ((int)(az_pair_peek(w) - want) >= 0) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(SLEEP);
+        if ((int)(az_pair_peek(w) - want) >= 0) return true;
+        if (az_pair_peek(abort) != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) {
+            __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+#endif
+
 __host__ __device__ inline unsigned long long az_splitmix64(unsigned long long z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

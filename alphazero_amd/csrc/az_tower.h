@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "az_dev.h"
 
 extern "C" {
 int  az_tower_configure(void);
@@ -18,6 +19,11 @@ void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const
                            const float* stem_b, const unsigned short* wpk, const float* bias,
                            const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,
                            unsigned long long* sat);
+// the tower half of the persistent pair (AzPairDev): returns the workgroups launched, 0 if it does not fit
+int  az_launch_tower_pair(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
+                          const float* stem_b, const unsigned short* wpk, const float* bias,
+                          const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,
+                          unsigned long long* sat, const AzPairDev* pr, int max_blocks);
 // sat: device counter of work items whose residual stream reached fp16's largest value (az_stats.saturated)
 void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,
                      float* value, int B, int N, int C_pad, int Gd, int c_out, int vd, unsigned long long* sat,

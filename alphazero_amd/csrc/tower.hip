@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "az_tower.h"
+#include "az_dev.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -1141,14 +1142,26 @@ __device__ __forceinline__ void fused_conv_taps16(AccTile16<J>& acc, int g, int 
 #ifndef AZ_TOWER_REG_CAP
 #define AZ_TOWER_REG_CAP __attribute__((amdgpu_num_vgpr(224)))
 #endif
-template <int PR, int J>
-__global__ void __launch_bounds__(256) AZ_TOWER_REG_CAP
-az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
-                      const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
-                      const float* __restrict__ bias, const float* __restrict__ hp,
-                      float* __restrict__ policy, float* __restrict__ value,
-                      int B, int N, int Gd, int n_layers, int bpt, unsigned long long* __restrict__ sat) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// WT: the policy and value go out write-through (agent-scope stores), for a reader on another CU inside this launch
+template <bool WT>
+__device__ __forceinline__ void fused_out(float* p, float v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// One tile (boards tile * bpt ...) through the whole tower; every thread of the workgroup calls it.
+// lds_warm: an earlier tile of this workgroup has left the bias table and the zeroed guard rows in LDS (nothing
+// after the set-up writes either).  next_seq / next_want / next_nb (WT only): the hand-over words of the boards
+// this workgroup takes next; wave 0 looks at them while the heads run and, if they are all there, issues the
+// acquire for them right away.  Returns that (wave 0 only): the next tile can then start without waiting.
+template <int PR, int J, bool WT>
+__device__ __forceinline__ bool
+fused_tile(unsigned char* smem, int tile, const uint8_t* planes, const unsigned short* __restrict__ stem_w,
+           const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
+           const float* __restrict__ bias, const float* __restrict__ hp,
+           float* policy, float* value,
+           int B, int N, int Gd, int n_layers, int bpt, unsigned long long* __restrict__ sat, int plane_stride,
+           bool lds_warm = false, const unsigned* next_seq = nullptr, unsigned next_want = 0u, int next_nb = 0) {
     constexpr int TM = 128 * J;                              // rows of the workgroup's tile
     constexpr int PW = 32 * J;                               // positions per wave
     const int W = N + 1, P = W * W, A = N * N;
@@ -1167,7 +1180,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int gc = gq < 2 ? gq ^ 1 : gq;                     // ... the group of four channels its accumulators hold
     const int koff = ((gq & 1) << 3) | ((gq & 2) << 1);      // ... the 16-byte piece its k slice starts from
     constexpr int NPB = 2 * J;                               // 16-position blocks of a wave
-    const int b0 = blockIdx.x * bpt;                         // first board of the tile
+    const int b0 = tile * bpt;                               // first board of the tile
     const int nb_here = min(bpt, B - b0);
     const int rows_here = nb_here * P;                       // tile rows that belong to boards
 #ifdef AZ_TOWER_TIMING
@@ -1182,18 +1195,23 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
     const int np = nb_here * 3 * A;                          // <= 768 plane bytes per tile
     uint8_t pl[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) pl[t] = tid + 256 * t < np ? planes[(size_t)b0 * 3 * A + tid + 256 * t] : (uint8_t)0;
+    for (int t = 0; t < 3; ++t) {                            // board k of the tile starts at byte k * plane_stride (3 A when packed)
+        const int i = tid + 256 * t, bi = i / (3 * A);
+        pl[t] = i < np ? planes[(size_t)(b0 + bi) * plane_stride + (i - bi * 3 * A)] : (uint8_t)0;
+    }
     uint4 sw[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) sw[t] = *(const uint4*)(stem_w + (size_t)(tid + 256 * t) * 8);
     // all biases into LDS once: the per-layer epilogue then never waits on HBM/L2
     const int nb4 = (n_layers + 1) * 32;                     // float4s: stem bias, then every conv's
+    if (!lds_warm) {
 #pragma unroll 3
-    for (int i = tid; i < nb4 + 32; i += 256)
-        ((float4*)sBias)[i] = i < 32 ? ((const float4*)stem_b)[i] : (i < nb4 ? ((const float4*)bias)[i - 32] : make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int i = tid; i < 2 * Gd * (A_STRIDE / 16); i += 256) {
-        const int r = i / (A_STRIDE / 16), c = i % (A_STRIDE / 16);
-        *(uint4*)(sA + (size_t)(r < Gd ? r : r + TM) * A_STRIDE + c * 16) = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < nb4 + 32; i += 256)
+            ((float4*)sBias)[i] = i < 32 ? ((const float4*)stem_b)[i] : (i < nb4 ? ((const float4*)bias)[i - 32] : make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int i = tid; i < 2 * Gd * (A_STRIDE / 16); i += 256) {
+            const int r = i / (A_STRIDE / 16), c = i % (A_STRIDE / 16);
+            *(uint4*)(sA + (size_t)(r < Gd ? r : r + TM) * A_STRIDE + c * 16) = make_uint4(0, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) if (tid + 256 * t < np) sP[tid + 256 * t] = pl[t];
@@ -1307,6 +1325,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         __syncthreads();
         TSTAMP(5 + 4 * b);
     }
+    bool next_ready = false;
     // ---- heads, on the activations still resident in LDS --------------------
     // PolicyHead (network.hpp:51-60): 1x1 conv -> softmax over each board's N*N cells.
     // ValueHead (network.hpp:75-83): 1x1 conv -> BN(1) -> ReLU -> fc1 -> ReLU -> fc2 -> softmax*2-1.
@@ -1319,6 +1338,10 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         float* s_red = s_part + 256;                 // [8]
         int* s_map = (int*)(s_red + 8);              // [A] cell -> padded-raster row
         typedef float f32x2 __attribute__((ext_vector_type(2)));
+        // the planes of the next tile were published most of a tile ago: one look now, under the heads' own latencies
+        unsigned next_v = 0u;
+        const bool next_look = WT && next_seq != nullptr && wv == 0 && lane < next_nb;
+        if (next_look) next_v = az_pair_peek(next_seq + lane);
         const float bp = hp[256], bvv = hp[257];
         const float* fc1t = hp + 258;
         const float* fc1b = fc1t + 64 * A;
@@ -1380,6 +1403,11 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
         }
         if (TM < 256 && tid < 256 - TM) { s_logit[TM + tid] = -3.4e38f; s_u[TM + tid] = 0.f; }
         for (int a = tid; a < A; a += 256) s_map[a] = (a / N) * W + (a % N);
+        if (WT && next_seq != nullptr && wv == 0) {                  // wave-uniform
+            next_ready = __ballot(next_look && (int)(next_v - next_want) < 0) == 0ull;
+            // the invalidate completes on its own; the wait for every store of the tile, at its end, covers it
+            if (next_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         __syncthreads();
         // softmax over each board's cells, reductions in a fixed order (deterministic bits)
         const int base = (r / P) * P;
@@ -1396,7 +1424,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             if (lane == 0) s_red[4 + wv] = t;
             __syncthreads();
             sum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-            if (cell) policy[(size_t)b0 * A + py * N + px] = e / sum;
+            if (cell) fused_out<WT>(&policy[(size_t)b0 * A + py * N + px], e / sum);
         } else {                                     // several small boards per tile
             mx = -3.4e38f;
             for (int k = 0; k < P; ++k) mx = fmaxf(mx, s_logit[base + k]);
@@ -1406,7 +1434,7 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
             __syncthreads();
             sum = 0.f;
             for (int k = 0; k < P; ++k) sum += s_logit[base + k];
-            if (cell) policy[(size_t)(b0 + r / P) * A + py * N + px] = e / sum;
+            if (cell) fused_out<WT>(&policy[(size_t)(b0 + r / P) * A + py * N + px], e / sum);
         }
         TSTAMP(44);
         for (int bi = 0; bi < nb_here; ++bi) {       // value head, one board at a time
@@ -1451,8 +1479,8 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
                     z0 += fc2b[0]; z1 += fc2b[1];
                     const float m2 = fmaxf(z0, z1);
                     const float e0 = expf(z0 - m2), e1 = expf(z1 - m2);
-                    value[2 * (size_t)(b0 + bi)] = e0 / (e0 + e1) * 2.f - 1.f;
-                    value[2 * (size_t)(b0 + bi) + 1] = e1 / (e0 + e1) * 2.f - 1.f;
+                    fused_out<WT>(&value[2 * (size_t)(b0 + bi)], e0 / (e0 + e1) * 2.f - 1.f);
+                    fused_out<WT>(&value[2 * (size_t)(b0 + bi) + 1], e1 / (e0 + e1) * 2.f - 1.f);
                 }
             }
             __syncthreads();
@@ -1462,6 +1490,89 @@ az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* 
 #ifdef AZ_TOWER_TIMING
     if (ts_blk >= 0 && tid == 0) az_tower_ts[ts_blk][62] = __builtin_amdgcn_s_memrealtime();
 #endif
+    return next_ready;
+}
+
+template <int PR, int J>
+__global__ void __launch_bounds__(256) AZ_TOWER_REG_CAP
+az_tower_fused_kernel(const uint8_t* __restrict__ planes, const unsigned short* __restrict__ stem_w,
+                      const float* __restrict__ stem_b, const unsigned short* __restrict__ wpk,
+                      const float* __restrict__ bias, const float* __restrict__ hp,
+                      float* __restrict__ policy, float* __restrict__ value,
+                      int B, int N, int Gd, int n_layers, int bpt, unsigned long long* __restrict__ sat) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fused_tile<PR, J, false>(smem, blockIdx.x, planes, stem_w, stem_b, wpk, bias, hp, policy, value, B, N, Gd, n_layers, bpt, sat, 3 * N * N);
+}
+
+// The tower half of the persistent pair (AzPairDev, az_dev.h): one workgroup per CU walks its tiles round after
+// round; a tile starts when the tree waves have published the planes of its boards and ends by publishing their
+// policy and value.  Nothing else couples the workgroups: no grid-wide step between rounds.
+// The arguments travel as one struct and are read from the kernel-argument segment again for every tile (scalar
+// loads behind an opaque pointer): held in registers across the tile loop they cost the tile body 40 scalar
+// registers it does not have.
+struct AzTowerPairArgs {
+    const uint8_t* planes; const unsigned short* stem_w; const float* stem_b; const unsigned short* wpk;
+    const float* bias; const float* hp; float* policy; float* value;
+    int B, N, Gd, n_layers, bpt, tiles;
+    unsigned long long* sat;
+    AzPairDev pr;
+};
+template <int PR, int J>
+__global__ void __launch_bounds__(256) AZ_TOWER_REG_CAP
+az_tower_pair_kernel(AzTowerPairArgs) {
+    typedef const __attribute__((address_space(4))) AzTowerPairArgs* KArgs;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_go;
+    KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int rounds = ka->pr.rounds, tiles = ka->tiles;
+    __builtin_amdgcn_s_setprio(3);                                       // ahead of the tree wave that shares this SIMD
+    if (threadIdx.x == 0) s_go = 0;                                      // 0: wait for the tile's planes, 1: already acquired, -1: leave
+    __syncthreads();
+    bool warm = false;
+    for (int i = 1; i <= rounds; ++i) {
+        for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+            asm volatile("" : "+s"(ka));                                 // forget what was loaded through it
+            int go = s_go;                                               // written in front of the last barrier
+            if (go == 0) {
+                __syncthreads();                                         // every wave has read s_go: wave 0 may rewrite it
+                const unsigned want = ka->pr.base + (unsigned)i;
+                const int b = t * ka->bpt + (int)threadIdx.x;
+                if (threadIdx.x < 64) {                                  // lane k of wave 0 stands for board k of the tile
+                    bool ok = true;
+                    // round 1 evaluates the planes that were there before the launch
+                    if ((int)threadIdx.x < ka->bpt && b < ka->B && i > 1 && !(ka->pr.flags & 1u))
+                        ok = az_pair_wait<4>(ka->pr.plane_seq + b, want, ka->pr.abort, ka->pr.timeout_ticks);
+                    const bool all_ok = __ballot(!ok) == 0ull;
+                    // the planes were written by other CUs: drop this CU's L1 copies before any wave loads them
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (threadIdx.x == 0) s_go = all_ok ? 1 : -1;
+                }
+                __syncthreads();
+                go = s_go;
+            }
+            if (go < 0) return;                                          // a wait ran out somewhere: leave
+            // what this workgroup takes next: its next tile of this round, else its first of the next round
+            int tn = t + (int)gridDim.x, in = i;
+            if (tn >= tiles) { tn = (int)blockIdx.x; in = i + 1; }
+            const bool look = in <= rounds && !(ka->pr.flags & 3u);
+            const bool pre = fused_tile<PR, J, true>(smem, t, ka->planes, ka->stem_w, ka->stem_b, ka->wpk, ka->bias, ka->hp, ka->policy,
+                                                     ka->value, ka->B, ka->N, ka->Gd, ka->n_layers, ka->bpt, ka->sat, ka->pr.plane_stride,
+                                                     warm, look ? ka->pr.plane_seq + tn * ka->bpt : nullptr, ka->pr.base + (unsigned)in,
+                                                     min(ka->bpt, ka->B - tn * ka->bpt));
+            warm = true;
+            // every wave's write-through stores have left (and wave 0's early acquire has completed) before the flags say so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) s_go = pre ? 1 : 0;
+            __syncthreads();
+            asm volatile("" : "+s"(ka));
+            {
+                const int b = t * ka->bpt + (int)threadIdx.x;
+                if ((int)threadIdx.x < ka->bpt && b < ka->B)
+                    __hip_atomic_store(ka->pr.eval_seq + b, ka->pr.base + (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------- heads
@@ -1793,6 +1904,8 @@ extern "C" int az_tower_configure(void) {
     SETA(az_heads_kernel<0>, 128 * 1024); SETA(az_heads_kernel<1>, 128 * 1024);
     SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
     SETA((az_tower_fused_kernel<0, 1>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1>), 160 * 1024);
+    SETA((az_tower_pair_kernel<0, 2>), 160 * 1024 - 64); SETA((az_tower_pair_kernel<1, 2>), 160 * 1024 - 64);
+    SETA((az_tower_pair_kernel<0, 1>), 160 * 1024 - 64); SETA((az_tower_pair_kernel<1, 1>), 160 * 1024 - 64);
 #undef SETA
     return (int)e;
 }
@@ -1855,6 +1968,19 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsig
             in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
 }
 
+// Tile height of the fused kernel for a batch
+static int fused_rows(int B, int P) {
+    int rows = TILE_M;
+    const char* force = getenv("AZ_FUSED_ROWS");
+    if (P <= 128) {
+        const int t256 = (B + TILE_M / P - 1) / (TILE_M / P), t128 = (B + 128 / P - 1) / (128 / P);
+        const int r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;
+        if (3 * r128 < 5 * r256) rows = 128;
+        if (force) rows = atoi(force) == 128 ? 128 : TILE_M;
+    }
+    return rows;
+}
+
 extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                                       const float* stem_b, const unsigned short* wpk, const float* bias,
                                       const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,
@@ -1863,14 +1989,7 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     // Tile height: 256 rows (four 16-position blocks per wave), or 128 rows where a whole board fits in 128
     // and the batch is too small to fill the chip with 256-row tiles.  A 128-row tile does half the MFMA
     // work per weight byte, so it costs ~0.6 of a 256-row tile, not 0.5: take it when it saves tile rounds.
-    int rows = TILE_M;
-    const char* force = getenv("AZ_FUSED_ROWS");             // "128" / "256": A/B and tests
-    if (P <= 128) {
-        const int t256 = (B + TILE_M / P - 1) / (TILE_M / P), t128 = (B + 128 / P - 1) / (128 / P);
-        const int r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;      // rounds of one tile per CU
-        if (3 * r128 < 5 * r256) rows = 128;
-        if (force) rows = atoi(force) == 128 ? 128 : TILE_M;
-    }
+    const int rows = fused_rows(B, P);                       // AZ_FUSED_ROWS = "128" / "256" forces one: A/B and tests
     const int bpt = rows / P;
     const int tiles = (B + bpt - 1) / bpt;
     const size_t sm = az_tower_fused_lds_bytes(N, n_layers, rows);
@@ -1880,6 +1999,30 @@ extern "C" void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* pl
     if (rows == 128) FUSED_LAUNCH(1); else FUSED_LAUNCH(2);
 #undef FUSED_LAUNCH
 #undef FUSED_ARGS
+}
+
+// The persistent form: at most `max_blocks` workgroups (one per CU), each walks tiles b, b + blocks, ... every
+// round.  Returns the number of workgroups launched, 0 when the kernel's LDS does not fit.
+extern "C" int az_launch_tower_pair(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
+                                    const float* stem_b, const unsigned short* wpk, const float* bias,
+                                    const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,
+                                    unsigned long long* sat, const AzPairDev* pr, int max_blocks) {
+    const int P = (N + 1) * (N + 1);
+    const int rows = fused_rows(B, P);
+    const int bpt = rows / P;
+    const int tiles = (B + bpt - 1) / bpt;
+    const size_t sm = az_tower_fused_lds_bytes(N, n_layers, rows);
+    if (sm > 160 * 1024 - 64 || bpt > 64) return 0;
+    const int blocks = tiles < max_blocks ? tiles : max_blocks;
+    AzTowerPairArgs ka;
+    ka.planes = planes; ka.stem_w = stem_w; ka.stem_b = stem_b; ka.wpk = wpk; ka.bias = bias; ka.hp = hp;
+    ka.policy = policy; ka.value = value; ka.B = B; ka.N = N; ka.Gd = Gd; ka.n_layers = n_layers; ka.bpt = bpt;
+    ka.tiles = tiles; ka.sat = sat; ka.pr = *pr;
+#define PAIR_LAUNCH(J_) do { if (prec == 1) hipLaunchKernelGGL((az_tower_pair_kernel<1, J_>), dim3(blocks), dim3(256), sm, s, ka); \
+                             else hipLaunchKernelGGL((az_tower_pair_kernel<0, J_>), dim3(blocks), dim3(256), sm, s, ka); } while (0)
+    if (rows == 128) PAIR_LAUNCH(1); else PAIR_LAUNCH(2);
+#undef PAIR_LAUNCH
+    return blocks;
 }
 
 extern "C" void az_launch_heads(hipStream_t s, int prec, const float* x, const float* hp, float* policy,

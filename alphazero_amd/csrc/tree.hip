@@ -606,12 +606,9 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells) {
 // ------------------------------------------------------------------ kernels
 // One lockstep round.  phase_mask bit0: apply the pending evaluation,
 // bit1: advance (finish search / play move / select the next leaf).
-extern "C" __global__ void __launch_bounds__(AZ_WAVE)
-az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void az_round_body(const AzTreeDev& d, int phase_mask, int mode, int g, unsigned char* smem) {
     uint8_t* s_cells = smem;
     int* s_old = (int*)(smem + AZ_CELLS_MAX);
-    const int g = g0 + blockIdx.x;                                      // a launch covers games [g0, g0 + gridDim.x)
     TTS(0);
     if (uni(d.status[g]) != AZ_ST_RUN) return;
     TTS(1);
@@ -650,6 +647,54 @@ az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
     for (int k = 0; k < d.L && k < owed; ++k)
         if (az_select(d, g, k, s_cells, s_old)) break;
     TTS(6);
+}
+
+extern "C" __global__ void __launch_bounds__(AZ_WAVE)
+az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    az_round_body(d, phase_mask, mode, g0 + blockIdx.x, smem);         // a launch covers games [g0, g0 + gridDim.x)
+}
+
+// The tree half of the persistent pair (AzPairDev, az_dev.h): a wave takes its games in turn, round after round;
+// a game's step runs as soon as that game's evaluation is there, whatever the other games are doing.  Same
+// az_round_body as the lockstep kernel, so a game's tree is the same bit for bit: games share no tree state.
+extern "C" __global__ void __launch_bounds__(AZ_WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))
+az_round_pair_kernel(AzTreeDev d, AzPairDev pr, int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int i = 1; i <= pr.rounds; ++i) {
+        const unsigned want = pr.base + (unsigned)i;
+        for (int g = blockIdx.x; g < d.G; g += gridDim.x) {
+            // the tree is never the hurry (its planes are wanted a whole tile later): poll seldom, stay out of the tower's way
+            const bool ok = az_pair_wait<100>(pr.eval_seq + g, want, pr.abort, pr.timeout_ticks);
+            if (__ballot(!ok) != 0ull) return;                          // a wait ran out somewhere: leave
+            // the evaluation was stored write-through by another CU: drop this CU's L1 copies before reading it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            az_round_body(d, 3, mode, g, smem);
+            __syncthreads();
+            // The leaf's planes go to the tower's CU as whole words stored write-through, which need no write-back of
+            // this XCD's L2 (a release fence would flush every tree wave's dirty edges, in the way of the towers'
+            // weight stream): read back what this wave wrote (it sees its own stores), pack, store, drain, flag.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const uint8_t* src = d.leaf_planes + (size_t)g * 3 * d.A;
+                unsigned* dst = pr.planes_wt + (size_t)g * (pr.plane_stride >> 2);
+                const int nw = (3 * d.A + 3) >> 2;
+                for (int w = threadIdx.x; w < nw; w += AZ_WAVE) {
+                    unsigned v = 0;
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * w + k < 3 * d.A) v |= (unsigned)src[4 * w + k] << (8 * k);
+                    __hip_atomic_store(dst + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(pr.plane_seq + g, want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pr.busy[g] += __builtin_amdgcn_s_memrealtime() - t0;
+            }
+        }
+    }
 }
 
 // search_probs entry: root reuse decision (mcts.hpp:121) for every game.
@@ -777,10 +822,14 @@ az_eval_hash_kernel(const uint8_t* planes, float* policy, float* value, int A) {
 #include "az_tree.h"
 
 static inline size_t tree_smem(const AzTreeDev&) { return AZ_SMEM_FIXED; }
+static_assert(AZ_SMEM_FIXED == AZ_TREE_SMEM_BYTES, "az_tree.h states the tree block's LDS");
 
 extern "C" int az_tree_configure(const AzTreeDev*) { return 0; }
 extern "C" void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode, int g0, int count) {
     hipLaunchKernelGGL(az_round_kernel, dim3(count), dim3(AZ_WAVE), tree_smem(*d), s, *d, phase_mask, mode, g0);
+}
+extern "C" void az_launch_round_pair(hipStream_t s, const AzTreeDev* d, const AzPairDev* pr, int mode, int blocks) {
+    hipLaunchKernelGGL(az_round_pair_kernel, dim3(blocks), dim3(AZ_WAVE), tree_smem(*d), s, *d, *pr, mode);
 }
 extern "C" void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget) {
     hipLaunchKernelGGL(az_begin_kernel, dim3(d->G), dim3(AZ_WAVE), tree_smem(*d), s, *d, budget);

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Self-play hot-path benchmark: MCTS simulations/s, whole job.
 
-One step = one move of the lockstep batch = `sims/move` passes of the hot path
+One step = one move of every game = `sims/move` passes of the hot path
 (env step -> PUCT select -> tower evaluation -> expand -> backup) over G
 concurrent 15x15 gomoku games per GPU, including the re-root that carries every
 tree over to the next move (BASELINE.json configs[2] sharded by game: 4096
-games over 8 GPUs = 512 per GPU; at N=1 the same 512-game shard).  Weak
-scaling: every rank owns its own games, there is no collective inside the
-timed region.
+games over 8 GPUs = 512 per GPU; at N=1 the same 512-game shard).  A step runs
+as ONE launch of the persistent tower / tree pair (az_selfplay_run_pair); the
+same games as lockstep launches are measured behind it, informationally (and
+are the headline with --lockstep, several contexts, --leaves > 1, or ranks that
+share a GPU).  Weak scaling: every rank owns its own games, there is no
+collective inside the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
@@ -205,13 +208,15 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs of BASELINE configs[1], [3], [4] that the default single-GPU run appends as other_configs")
     ap.add_argument("--contexts", type=int, default=1,
-                    help="split the GPU's games over this many engine contexts (own stream each) so that one "
-                         "context's tree kernel overlaps another's tower")
+                    help="split the GPU's games over this many engine contexts (own stream each)")
     ap.add_argument("--leaves", type=int, default=1,
                     help="descents per tree per round (1 = the reference at nthreads=1, bit-exact; >1 = its nthreads=L "
                          "in a fixed order, evaluation batch = games x leaves)")
-    ap.add_argument("--no-overlap-probe", action="store_true",
-                    help="skip the second, informational measurement with two contexts per GPU")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="time the rounds as lockstep launches (evaluator, tree round, ...) instead of one launch of the "
+                         "persistent tower / tree pair per step")
+    ap.add_argument("--no-lockstep-probe", action="store_true",
+                    help="skip the second, informational measurement of the same games as lockstep launches")
     ap.add_argument("--full-games", type=float, default=40.0,
                     help="after the timed region keep playing for this many seconds and report finished games/hour")
     ap.add_argument("--config", type=int, choices=[1, 2, 3, 4], default=None,
@@ -262,91 +267,142 @@ def main():
     prec = {"fp16": capi.AZ_PREC_FP16, "bf16": capi.AZ_PREC_BF16, "fp16x3": capi.AZ_PREC_FP16X3}[args.precision]
     NC = args.contexts
     assert G % NC == 0
-    engs = [capi.Engine(N, K, G // NC, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
-                        device=local_rank, game_slot_base=rank * G + i * (G // NC), precision=prec,
-                        leaves_per_round=args.leaves) for i in range(NC)]
-    eng = engs[0]
     # weights: rank 0 builds the synthetic blob, RCCL broadcasts it (the only collective of this path)
-    nw = eng.weights_size()
+    blob = wt = None
     if use_dist:
+        nw = synth.blob_size(N, 3, Cs) if hasattr(synth, "blob_size") else len(synth.make_blob(N, 3, Cs, 0))
         wt = torch.empty(nw, dtype=torch.float32, device=cdev)
         if rank == 0:
             wt.copy_(torch.from_numpy(synth.make_blob(N, 3, Cs, 0)))
         dist.broadcast(wt, 0)
         wt = wt.cuda()
         torch.cuda.synchronize()
-        for e in engs:
-            e.load_weights_dev(wt.data_ptr(), nw)
     else:
         blob = synth.make_blob(N, 3, Cs, 0)
-        for e in engs:
-            e.load_weights(blob)
 
-    def run(rounds):
-        # launches are asynchronous: interleave the contexts in slices so every stream stays fed
-        done = 0
-        while done < rounds:
-            k = min(16, rounds - done)
-            for e in engs:
-                e.selfplay_run(k)
-            done += k
+    def make_engines():
+        es = [capi.Engine(N, K, G // NC, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
+                          device=local_rank, game_slot_base=rank * G + i * (G // NC), precision=prec,
+                          leaves_per_round=args.leaves) for i in range(NC)]
+        for e in es:
+            if use_dist:
+                e.load_weights_dev(wt.data_ptr(), e.weights_size())
+            else:
+                e.load_weights(blob)
+        return es
 
-    def barrier():
-        for e in engs:
-            e.sync()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # one step = one move's worth of lockstep rounds (sims/move descents per game, L per round)
+    # one step = one move's worth of rounds (sims/move descents per game, L per round)
     rps = (budget + args.leaves - 1) // args.leaves
-    # HIP events around every `every`-th evaluator call and tree round of the timed region, within the
-    # library's event pool (4096 spans): every launch when the region is short
-    spans_per_round = 3 if Cs[0] <= 128 and N <= 15 and prec != capi.AZ_PREC_FP16X3 else 2 * (len(Cs) - 1) + 2
-    every = max(1, -(-(args.steps * rps * spans_per_round) // 3600))
-    for e in engs:
-        e.selfplay_begin(budget)
-    run(args.warmup * rps)
-    eng.profile_enable(every)
-    barrier()
     TALLY = ("descents", "tree_levels", "children_scanned", "children_expanded", "evals")
-    st0 = [e.stats() for e in engs]
-    sims0 = sum(x["sims_backed_up"] for x in st0)
-    tally0 = {k: sum(x[k] for x in st0) for k in TALLY}
-    t0 = time.perf_counter()
-    run(args.steps * rps)
-    barrier()
-    el = time.perf_counter() - t0
-    el_local = el
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    prof = eng.profile_read()
-    fused, batch = eng.tower_is_fused(), eng.selfplay_batch()
-    sts = [e.stats() for e in engs]
-    st = {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
-    sims_local = st["sims_backed_up"] - sims0              # simulations this rank backed up inside the timed region
-    tally = {k: st[k] - tally0[k] for k in TALLY}          # what this rank's tree kernel walked, read and wrote
-    if use_dist:
-        t = torch.tensor([sims_local], dtype=torch.int64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        sims_all = int(t.item())
-        # what each rank contributed: its own device counter and its own clock (value = sum / max)
-        mine = torch.tensor([float(sims_local), el_local], dtype=torch.float64, device=cdev)
-        allr = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = {"sims": [int(x[0].item()) for x in allr], "seconds": [float(x[1].item()) for x in allr]}
-    else:
-        sims_all = sims_local
-        per_rank = None
-    if st["error_games"]:
-        raise SystemExit("tree arena overflow in %d games" % st["error_games"])
+
+    def agg(sts):
+        return {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
+
+    def timed_leg(pair):
+        """warm-up + the timed region, either with every step as ONE launch of the persistent tower / tree pair
+        (az_selfplay_run_pair) or as lockstep launches (az_selfplay_run: evaluator, tree round, evaluator, ...)."""
+        es = make_engines()
+
+        def run(rounds):
+            if pair:
+                for done in range(0, rounds, rps):
+                    es[0].selfplay_run_pair(min(rps, rounds - done))
+                return
+            # launches are asynchronous: interleave the contexts in slices so every stream stays fed
+            done = 0
+            while done < rounds:
+                k = min(16, rounds - done)
+                for e in es:
+                    e.selfplay_run(k)
+                done += k
+
+        def barrier():
+            for e in es:
+                e.sync()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for e in es:
+            e.selfplay_begin(budget)
+        # the pair needs its two kernels resident together; a rank that does not get that says so here, and then
+        # every rank leaves the leg together (the collectives below stay matched)
+        ok, why = 1, ""
+        try:
+            run(args.warmup * rps)
+            for e in es:
+                e.sync()
+        except capi.AzError as ex:
+            if not pair:
+                raise
+            ok, why = 0, str(ex)
+        if use_dist and pair:
+            t = torch.tensor([ok], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0 and ok:
+                ok, why = 0, "another rank's persistent pair did not run"
+        if not ok:
+            for e in es:
+                e.close()
+            return {"error": why}
+        # HIP events around every `every`-th evaluator call and tree round of the timed region, within the
+        # library's event pool (4096 spans): every launch when the region is short (every launch of the pair)
+        spans_per_round = 3 if Cs[0] <= 128 and N <= 15 and prec != capi.AZ_PREC_FP16X3 else 2 * (len(Cs) - 1) + 2
+        every = 1 if pair else max(1, -(-(args.steps * rps * spans_per_round) // 3600))
+        es[0].profile_enable(every)
+        barrier()
+        st0 = agg([e.stats() for e in es])
+        t0 = time.perf_counter()
+        run(args.steps * rps)
+        barrier()
+        el = time.perf_counter() - t0
+        st = agg([e.stats() for e in es])
+        leg = {"pair": pair, "engs": es, "run": run, "el_local": el, "el": el, "every": every, "st": st,
+               "sims_local": st["sims_backed_up"] - st0["sims_backed_up"],
+               "tally": {k: st[k] - st0[k] for k in TALLY},
+               "prof": es[0].pair_read() if pair else es[0].profile_read(),
+               "fused": es[0].tower_is_fused(), "batch": es[0].selfplay_batch()}
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            leg["el"] = float(t.item())
+            t = torch.tensor([leg["sims_local"]], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            leg["sims_all"] = int(t.item())
+            # what each rank contributed: its own device counter and its own clock (value = sum / max)
+            mine = torch.tensor([float(leg["sims_local"]), el], dtype=torch.float64, device=cdev)
+            allr = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            leg["per_rank"] = {"sims": [int(x[0].item()) for x in allr], "seconds": [float(x[1].item()) for x in allr]}
+        else:
+            leg["sims_all"] = leg["sims_local"]
+            leg["per_rank"] = None
+        if st["error_games"]:
+            raise SystemExit("tree arena overflow in %d games" % st["error_games"])
+        return leg
+
+    # The headline runs every step as one launch of the persistent pair wherever that form exists (the one-launch
+    # tower, one leaf per round, one context) and each rank has its GPU to itself; --lockstep, several contexts,
+    # --leaves > 1 or ranks sharing a GPU (the gloo rehearsal) take the lockstep launches.
+    probe = capi.Engine(N, K, 1, Cs=Cs, max_budget=2, precision=prec, device=local_rank)
+    fused_tower = probe.tower_is_fused()
+    probe.close()
+    want_pair = fused_tower and NC == 1 and args.leaves == 1 and not args.lockstep and backend != "gloo"
+    pair_fallback = None
+    leg = timed_leg(True) if want_pair else None
+    if leg is not None and "error" in leg:
+        pair_fallback = leg["error"]
+        leg = None
+    if leg is None:
+        leg = timed_leg(False)
+    engs, run, el, st = leg["engs"], leg["run"], leg["el"], leg["st"]
+    sims_all, per_rank, prof, tally = leg["sims_all"], leg["per_rank"], leg["prof"], leg["tally"]
+    fused, batch, every = leg["fused"], leg["batch"], leg["every"]
     games_info = None
     if args.full_games > 0:
         # whole games: keep the same engine running, count games finished per wall second
-        eng.profile_enable(0)
+        engs[0].profile_enable(0)
         t1 = time.perf_counter()
         g0, m0, s0fg = st["games"], st["moves"], st["sims_backed_up"]
         while time.perf_counter() - t1 < args.full_games:
@@ -354,8 +410,7 @@ def main():
             for e in engs:
                 e.replay_drain(1 << 15)
         el2 = time.perf_counter() - t1
-        sts2 = [e.stats() for e in engs]
-        st2 = {k: sum(x[k] for x in sts2) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts2) for k in sts2[0]}
+        st2 = agg([e.stats() for e in engs])
         ng, nm, ns = st2["games"] - g0, st2["moves"] - m0, st2["sims_backed_up"] - s0fg
         if use_dist:                                       # whole-job totals
             t = torch.tensor([ng, nm, ns], dtype=torch.int64, device=cdev)
@@ -370,43 +425,18 @@ def main():
                       "moves_per_s": nm / el2, "mean_game_length": nm / ng if ng else None,
                       "max_tree_nodes": st2["max_nodes"], "error_games": st2["error_games"],
                       "tree_restarts": st2["tree_restarts"]}
+    for e in engs:
+        e.close()
+    engs = []
 
-    overlap = None
-    if NC == 1 and not args.no_overlap_probe and G % 2 == 0:
-        # Informational second measurement, never `value`: the same games as two contexts on two streams.
-        # A tree block fits on a CU beside a resident tower workgroup, so one context's tree round runs
-        # under the other's tower.  Launches of the two contexts overlap in time, which is why the
-        # headline and its roofline stay on the single-stream run above (clean per-launch durations).
-        for e in engs:
+    # Informational second measurement, never `value`: the same games (same seeds, same number of timed rounds, same
+    # device, same call) as lockstep launches.  It prices the tree round as a kernel of its own (`tree_roofline`)
+    # and says what the persistent pair buys.
+    lock = None
+    if leg["pair"] and not args.no_lockstep_probe:
+        lock = timed_leg(False)
+        for e in lock["engs"]:
             e.close()
-        engs = [capi.Engine(N, K, G // 2, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
-                            device=local_rank, game_slot_base=rank * G + i * (G // 2), precision=prec,
-                            leaves_per_round=args.leaves) for i in range(2)]
-        for e in engs:
-            if use_dist:
-                e.load_weights_dev(wt.data_ptr(), nw)
-            else:
-                e.load_weights(blob)
-            e.selfplay_begin(budget)
-        run(args.warmup * rps)
-        barrier()
-        s0 = sum(e.stats()["sims_backed_up"] for e in engs)
-        t1 = time.perf_counter()
-        run(args.steps * rps)
-        barrier()
-        el2 = time.perf_counter() - t1
-        s1 = sum(e.stats()["sims_backed_up"] for e in engs) - s0
-        if use_dist:
-            t = torch.tensor([el2], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-            t = torch.tensor([s1], dtype=torch.int64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            s1 = int(t.item())
-        overlap = {"contexts_per_gpu": 2, "value": s1 / el2, "unit": "sims/s", "ms_per_step": el2 / args.steps * 1e3,
-                   "ms_per_round": el2 / (args.steps * rps) * 1e3,
-                   "note": "same games as two contexts on two streams (bench.py --contexts 2): tree rounds run under the "
-                           "other context's tower; informational, launches overlap so no per-launch roofline here"}
 
     if rank == 0:
         A = N * N
@@ -418,9 +448,9 @@ def main():
         if fused:                           # stem + all 2*num_res convs in one launch
             conv_flops = (conv_flops * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C * B) / NC   # per launch of one context
             kernel = "az_tower_fused_kernel"
-        conv_tflops = conv_flops / (prof["conv_avg_us"] * 1e-6) / 1e12 if prof["conv_avg_us"] > 0 else 0.0
-        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command
-        # (tools/profile_bench.sh); only valid for the workload they were collected on
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of the lockstep form of this command
+        # (tools/profile_bench.sh; counter collection serialises launches, which the pair cannot run under); only
+        # valid for the workload they were collected on.  A pair launch walks the same tiles `rps` times.
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj) and (N, G, budget, NC, args.leaves) == (15, 512, 800, 1, 1):
@@ -428,34 +458,27 @@ def main():
                 traffic = json.load(open(tj))["kernels"][kernel]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
-        line = {
-            "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-            "step": "one move of every game: %d lockstep rounds (%d sims/move, %d per round), re-root included" % (rps, budget, args.leaves),
-            "rounds_per_step": rps, "ms_per_round": el / (args.steps * rps) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
-                                   "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
-                       "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world,
-                       "contexts_per_gpu": NC, "leaves_per_round": args.leaves},
-            "moves_per_s": sims / el / budget,
-            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": conv_tflops,
-                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": traffic, "avg_launch_us": prof["conv_avg_us"], "launches_sampled": prof["conv_launches"],
-                         "flops_per_launch": conv_flops,
-                         # informational: a bare MFMA loop at the issue floor reaches this on random bf16 operands
-                         # (the chip lowers its clock under MFMA load; tools/microbench/mfma_power.hip); `peak` and
-                         # `frac` stay priced against the datasheet's dense peak
-                         "bare_mfma_loop_on_random_data_tflops": 1830.0,
-                         "tree_round_avg_us": max(prof["tree_avg_us"] - prof["empty_span_us"], 0.0)},
-        }
-        # Tree kernel against the HBM roofline: algorithmic bytes = 12 B (p, n, v) per child edge read at
-        # every level of every descent + 24 B per level (virtual-loss write + backup read-modify-write) +
-        # 16 B per child edge written by an expansion + per evaluated leaf its planes (3A B) out and its
-        # policy and value (4A + 8 B) in; counted on the device (az_stats), rank 0's games, per launch.
-        if tally["descents"] > 0 and prof["tree_avg_us"] > 0:
-            tree_bytes = (12.0 * tally["children_scanned"] + 24.0 * tally["tree_levels"] + 16.0 * tally["children_expanded"]
-                          + tally["evals"] * (7.0 * A + 8.0)) / (args.steps * rps) / NC
+
+        def tower_roofline(us, launches, flops, name, tr):
+            tf = flops / (us * 1e-6) / 1e12 if us > 0 else 0.0
+            return {"bound": "mfma", "kernel": name, "achieved": tf,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": tr, "avg_launch_us": us, "launches_sampled": launches, "flops_per_launch": flops,
+                    # informational: a bare MFMA loop at the issue floor reaches this on random bf16 operands
+                    # (the chip lowers its clock under MFMA load; tools/microbench/mfma_power.hip); `peak` and
+                    # `frac` stay priced against the datasheet's dense peak
+                    "bare_mfma_loop_on_random_data_tflops": 1830.0}
+
+        def tree_roofline(lg):
+            # Tree kernel against the HBM roofline: algorithmic bytes = 12 B (p, n, v) per child edge read at
+            # every level of every descent + 24 B per level (virtual-loss write + backup read-modify-write) +
+            # 16 B per child edge written by an expansion + per evaluated leaf its planes (3A B) out and its
+            # policy and value (4A + 8 B) in; counted on the device (az_stats), rank 0's games, per launch.
+            tl, pf = lg["tally"], lg["prof"]
+            if not (tl["descents"] > 0 and pf["tree_avg_us"] > 0):
+                return None
+            tree_bytes = (12.0 * tl["children_scanned"] + 24.0 * tl["tree_levels"] + 16.0 * tl["children_expanded"]
+                          + tl["evals"] * (7.0 * A + 8.0)) / (args.steps * rps) / NC
             tree_traffic = None
             if traffic is not None:
                 try:
@@ -464,35 +487,75 @@ def main():
                     tree_traffic = None
             # a span of two event records over-states a short kernel: the empty spans taken right behind the sampled
             # rounds say by how much (rocprofv3's kernel duration agrees with the difference)
-            tree_us = max(prof["tree_avg_us"] - prof["empty_span_us"], 1e-3)
+            tree_us = max(pf["tree_avg_us"] - pf["empty_span_us"], 1e-3)
             gbs = tree_bytes / (tree_us * 1e-6) / 1e9
-            line["tree_roofline"] = {
-                "bound": "hbm", "kernel": "az_round_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": tree_traffic, "avg_launch_us": tree_us,
-                "event_span_us": prof["tree_avg_us"], "empty_event_span_us": prof["empty_span_us"],
-                "launches_sampled": prof["tree_launches"], "bytes_per_launch": tree_bytes,
-                "mean_depth": tally["tree_levels"] / tally["descents"],
-                "mean_children_per_level": tally["children_scanned"] / max(1, tally["tree_levels"]),
-                "note": "a chain of dependent loads, one per tree level: latency-bound, 512 one-wave blocks"}
+            return {"bound": "hbm", "kernel": "az_round_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": tree_traffic, "avg_launch_us": tree_us,
+                    "event_span_us": pf["tree_avg_us"], "empty_event_span_us": pf["empty_span_us"],
+                    "launches_sampled": pf["tree_launches"], "bytes_per_launch": tree_bytes,
+                    "mean_depth": tl["tree_levels"] / tl["descents"],
+                    "mean_children_per_level": tl["children_scanned"] / max(1, tl["tree_levels"]),
+                    "note": "a chain of dependent loads, one per tree level: latency-bound, 512 one-wave blocks"}
+
+        if leg["pair"]:
+            step = ("one move of every game: %d rounds (%d sims/move, 1 per round) as ONE launch of the persistent tower / tree "
+                    "pair (az_tower_pair_kernel beside az_round_pair_kernel), re-root included" % (rps, budget))
+            roof = tower_roofline(prof["launch_avg_us"], prof["launches"], conv_flops * rps, "az_tower_pair_kernel",
+                                  traffic * rps if traffic is not None else None)
+            roof["rounds_per_launch"] = rps
+            roof["tree_step_avg_us"] = prof["tree_step_avg_us"]
+            roof["note"] = ("a launch walks every game's tile %d times and ends when the last game's last evaluation is out: its duration "
+                            "includes the hand-over waits, so `frac` is the whole round's MFMA fraction; a game's tree step (tree_step_avg_us, "
+                            "timed inside the kernel) runs under another game's tile" % rps)
+        else:
+            step = "one move of every game: %d lockstep rounds (%d sims/move, %d per round), re-root included" % (rps, budget, args.leaves)
+            roof = tower_roofline(prof["conv_avg_us"], prof["conv_launches"], conv_flops, kernel, traffic)
+            roof["tree_round_avg_us"] = max(prof["tree_avg_us"] - prof["empty_span_us"], 0.0)
+        line = {
+            "metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "step": step, "rounds_per_step": rps, "ms_per_round": el / (args.steps * rps) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "gomoku %dx%d self-play, %d concurrent games per GPU, %d sims/move, NetConfig-2 tower "
+                                   "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
+                       "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world,
+                       "contexts_per_gpu": NC, "leaves_per_round": args.leaves,
+                       "rounds_as": "persistent pair" if leg["pair"] else "lockstep launches"},
+            "moves_per_s": sims / el / budget,
+            "roofline": roof,
+        }
+        if pair_fallback is not None:
+            line["persistent_pair_not_used"] = pair_fallback
+        if not leg["pair"]:
+            tr = tree_roofline(leg)
+            if tr is not None:
+                line["tree_roofline"] = tr
+        elif lock is not None:
+            # the same games as lockstep launches: the tree round as a kernel of its own, and the A/B
+            tr = tree_roofline(lock)
+            if tr is not None:
+                line["tree_roofline"] = tr
+            lp = lock["prof"]
+            lr = tower_roofline(lp["conv_avg_us"], lp["conv_launches"], conv_flops, kernel, traffic)
+            line["lockstep_launches"] = {
+                "value": lock["sims_all"] / lock["el"], "unit": "sims/s", "ms_per_round": lock["el"] / (args.steps * rps) * 1e3,
+                "pair_over_lockstep": (sims / el) / (lock["sims_all"] / lock["el"]),
+                "roofline": lr, "tree_round_avg_us": max(lp["tree_avg_us"] - lp["empty_span_us"], 0.0),
+                "note": "informational: the same games, seeds and number of timed rounds on the same device in the same call, every round "
+                        "as two launches on one stream (az_tower_fused_kernel, az_round_kernel); `tree_roofline` is taken here"}
         line["consistency"] = {"timed_region_s": el, "rounds_timed": args.steps * rps, "profile_every": every,
                                "sims_per_s_of_full_games_phase": games_info["sims_per_s"] if games_info else None}
         if per_rank is not None:
             line["per_rank"] = per_rank
         line["full_games"] = games_info
-        line["two_context_overlap"] = overlap
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, N, K, budget, 16)
-        for e in engs:
-            e.close()
-        engs = []
         if world == 1 and not args.no_other_configs and args.config is None and (N, G, budget, NC, args.leaves) == (15, 512, 800, 1, 1):
             try:
                 line["other_configs"] = other_configs(local_rank)
             except Exception as ex:  # noqa: BLE001  (the headline stands on its own)
                 line["other_configs"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
-    for e in engs:
-        e.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -222,6 +222,22 @@ int az_tree_dump(az_ctx*, int game, int node_cap, int edge_cap, int32_t* n_nodes
  * game end attach rewards, restart).  Rows accumulate in a device ring. */
 int az_selfplay_begin(az_ctx*, int iter_budget);
 int az_selfplay_run(az_ctx*, int rounds);
+/* The same `rounds` rounds (generate.cpp:72-120; per search mcts.hpp:105-155) as ONE launch of two persistent
+ * kernels that run side by side: the tower, one workgroup per CU walking its boards round after round, and the tree
+ * waves, one per CU beside it.  A game's next evaluation starts as soon as that game's select has published its
+ * planes, and its next select as soon as its evaluation is there: the tree work of one game runs under the tower
+ * work of another and no launch boundary separates rounds.  Games share no tree state, so every game's trees, rows
+ * and counters are those of az_selfplay_run bit for bit (rows of different games may reach the ring in another
+ * order).  Needs the one-launch tower (az_tower_is_fused), leaves_per_round 1 and the GPU to itself: the two kernels
+ * wait for each other in memory, so both must be resident at once.  If they are not (another process or context on
+ * the GPU, a profiler that serialises launches), a wait runs out after AZ_PAIR_TIMEOUT_MS (default 4000), both
+ * kernels leave, and az_sync / az_get_stats / az_pair_read return AZ_E_STATE from then on.
+ * With AZ_PAIR=1 in the environment az_selfplay_run takes this path whenever the context can. */
+int az_selfplay_run_pair(az_ctx*, int rounds);
+/* What the pair launches since az_profile_enable / az_selfplay_begin took: mean duration of the sampled tower
+ * launches (HIP events on the context's stream), how many were sampled and the rounds they ran, and the mean time a
+ * tree wave worked on one game's step (100 MHz clock inside the kernel, waits excluded; since az_selfplay_begin). */
+int az_pair_read(az_ctx*, double* launch_avg_us, int64_t* launches, int64_t* rounds, double* tree_step_avg_us);
 /* Drain finished rows: cells u8 [n,N*N] (0/1/2), to_move u8 [n], policy f32
  * [n,N*N], reward f32 [n,2] (replay.hpp:56-60,62-79 before symmetry expansion).
  * Returns the number of rows copied (<= cap) or a negative error. */

@@ -307,7 +307,7 @@ def test_bench_with_eight_ranks_prints_one_line_that_adds_up():
     env = dict(os.environ, AZ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
-           "--games", "32", "--budget", "32", "--board", "9", "--full-games", "0", "--no-overlap-probe"]
+           "--games", "32", "--budget", "32", "--board", "9", "--full-games", "0", "--no-lockstep-probe"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -1,0 +1,127 @@
+"""The persistent tower / tree pair (az_selfplay_run_pair) against the lockstep rounds (az_selfplay_run): the same
+games bit for bit -- counters, whole tree arenas, replay rows -- and a hand-over wait that runs out drains both
+kernels and is reported, instead of hanging the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from alphazero_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_key(cells, tm, pol, rew):
+    return sorted((cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm)))
+
+
+def _engine(N, K, G, budget, seed=5):
+    e = capi.Engine(N, K, G, Cs=synth.NETCONFIG2, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=seed)
+    e.load_weights(synth.make_blob(N, 3, synth.NETCONFIG2, 0))
+    e.selfplay_begin(budget)
+    return e
+
+
+# (N, K, games, sims/move, lockstep rounds, the same rounds as pair launches)
+CASES = [
+    (9, 5, 24, 32, 40, [1, 7, 32]),          # 128-row tiles, launches of one round and of many
+    (15, 5, 16, 24, 400, [400]),             # 256-row tiles = one game per workgroup; 240 moves with re-roots
+    (15, 5, 300, 40, 200, [50, 150]),        # more games than CUs: workgroups and tree waves take two games each
+    (5, 4, 37, 16, 300, [100, 200]),         # seven boards per tile, ragged last tile, whole games and restarts
+]
+
+
+@pytest.mark.parametrize("N,K,G,budget,rounds,chunks", CASES)
+def test_pair_plays_the_same_games_as_lockstep_rounds(N, K, G, budget, rounds, chunks):
+    a, b = _engine(N, K, G, budget), _engine(N, K, G, budget)
+    try:
+        a.selfplay_run(rounds)
+        a.sync()
+        for ch in chunks:
+            b.selfplay_run_pair(ch)
+        b.sync()
+        sa, sb = a.stats(), b.stats()
+        assert sa == sb
+        assert sa["rounds"] == rounds and sa["error_games"] == 0
+        for g in range(G):
+            da, db = a.tree_dump(g), b.tree_dump(g)
+            for k in da:
+                assert np.array_equal(da[k], db[k]), "tree of game %d differs in %s" % (g, k)
+        ra, rb = _rows_key(*a.replay_drain()), _rows_key(*b.replay_drain())
+        assert ra == rb
+        if N == 5:
+            assert sa["games"] > 0 and len(ra) > 0
+        pr = b.pair_read()
+        assert 0.0 < pr["tree_step_avg_us"] < 1000.0
+    finally:
+        a.close()
+        b.close()
+
+
+def test_pair_and_lockstep_rounds_mix_on_one_context():
+    N, K, G, budget = 9, 5, 40, 24
+    a, b = _engine(N, K, G, budget), _engine(N, K, G, budget)
+    try:
+        a.selfplay_run(150)
+        b.selfplay_run(20)
+        b.selfplay_run_pair(60)
+        b.selfplay_run(30)
+        b.selfplay_run_pair(40)
+        a.sync()
+        b.sync()
+        assert a.stats() == b.stats()
+        for g in range(G):
+            da, db = a.tree_dump(g), b.tree_dump(g)
+            for k in da:
+                assert np.array_equal(da[k], db[k])
+        assert _rows_key(*a.replay_drain()) == _rows_key(*b.replay_drain())
+    finally:
+        a.close()
+        b.close()
+
+
+def test_pair_needs_the_one_launch_tower_and_one_leaf_per_round():
+    e = capi.Engine(9, 5, 8, Cs=synth.NETCONFIG2, max_budget=16, noise_mode=capi.AZ_NOISE_DEVICE, leaves_per_round=2)
+    e.load_weights(synth.make_blob(9, 3, synth.NETCONFIG2, 0))
+    e.selfplay_begin(16)
+    with pytest.raises(capi.AzError, match="leaves_per_round"):
+        e.selfplay_run_pair(4)
+    e.close()
+    e = capi.Engine(9, 5, 8, eval_mode=capi.AZ_EVAL_HASH, max_budget=16, noise_mode=capi.AZ_NOISE_DEVICE)
+    e.selfplay_begin(16)
+    with pytest.raises(capi.AzError, match="one launch"):
+        e.selfplay_run_pair(4)
+    e.close()
+
+
+def test_a_wait_that_runs_out_drains_both_kernels_and_is_reported():
+    """Without its tree kernel the tower's first wait can never be answered: after AZ_PAIR_TIMEOUT_MS every
+    workgroup leaves, the launch ends, and the context says what happened until self-play is begun again."""
+    N, K, G, budget = 9, 5, 24, 16
+    e = _engine(N, K, G, budget)
+    old = {k: os.environ.get(k) for k in ("AZ_PAIR_FLAGS", "AZ_PAIR_TIMEOUT_MS")}
+    try:
+        os.environ["AZ_PAIR_FLAGS"] = "4"                    # launch no tree kernel
+        os.environ["AZ_PAIR_TIMEOUT_MS"] = "30"
+        e.selfplay_run_pair(5)
+        with pytest.raises(capi.AzError, match="ran out"):
+            e.sync()
+        with pytest.raises(capi.AzError, match="ran out"):
+            e.stats()
+        os.environ["AZ_PAIR_FLAGS"] = "0"
+        os.environ["AZ_PAIR_TIMEOUT_MS"] = "4000"
+        e.selfplay_begin(budget)                             # a fresh start clears the flag
+        e.selfplay_run_pair(40)
+        e.sync()
+        ref = _engine(N, K, G, budget)
+        ref.selfplay_run(40)
+        ref.sync()
+        assert e.stats()["sims_backed_up"] == ref.stats()["sims_backed_up"] > 0
+        ref.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        e.close()
