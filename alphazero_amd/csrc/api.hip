@@ -921,6 +921,10 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     AZCHK(check_budget(c, budget, 2));
     c->d.budget = budget > 1 ? budget : 1;
     c->mode = AZ_MODE_SELFPLAY;
+    if (const char* e = getenv("AZ_CHAIN")) {               // az_selfplay_chain from the environment (host programs, A/B runs)
+        const int k = atoi(e);
+        if (c->d.L == 1 && k >= 0 && k <= 64) c->d.chain = k;
+    }
     HIPCHK(hipMemsetAsync(c->d.counters, 0, 16 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d.g_ctr, 0, sizeof(unsigned long long) * AZ_GC_STRIDE * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.g_hw_nodes, 0, sizeof(int) * c->cfg.G, c->stream));
@@ -955,6 +959,14 @@ static int pair_check(az_ctx* c) {
     if (ab) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out: the two kernels were not "
                                      "resident together (another process on this GPU, or a profiler that serialises launches); "
                                      "the games of this context are no longer in step -- run such set-ups with az_selfplay_run");
+    return AZ_OK;
+}
+
+extern "C" int az_selfplay_chain(az_ctx* c, int max_chained) {
+    NEED(c); NEED_GAMES(c);
+    if (max_chained < 0 || max_chained > 64) return fail(AZ_E_ARG, "max_chained %d out of range (0..64)", max_chained);
+    if (c->d.L != 1 && max_chained) return fail(AZ_E_STATE, "chained terminal simulations need leaves_per_round 1");
+    c->d.chain = max_chained;
     return AZ_OK;
 }
 

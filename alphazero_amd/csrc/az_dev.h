@@ -38,6 +38,7 @@ struct AzTreeDev {
     unsigned long long seed;
     int slot_base;
     int budget;                 // selfplay: iter_budget of every search
+    int chain;                  // simulations ending in a stored terminal leaf (no evaluation) a round may run back to back
 
     // real game (= root position)
     uint8_t*  cells;            // [G][A]

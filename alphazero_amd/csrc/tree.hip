@@ -606,7 +606,7 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells) {
 // ------------------------------------------------------------------ kernels
 // One lockstep round.  phase_mask bit0: apply the pending evaluation,
 // bit1: advance (finish search / play move / select the next leaf).
-__device__ __forceinline__ void az_round_body(const AzTreeDev& d, int phase_mask, int mode, int g, unsigned char* smem) {
+__device__ __forceinline__ void az_round_once(const AzTreeDev& d, int phase_mask, int mode, int g, unsigned char* smem) {
     uint8_t* s_cells = smem;
     int* s_old = (int*)(smem + AZ_CELLS_MAX);
     TTS(0);
@@ -649,21 +649,47 @@ __device__ __forceinline__ void az_round_body(const AzTreeDev& d, int phase_mask
     TTS(6);
 }
 
+// A game's round.  A descent that ends in a terminal leaf whose reward is already stored needs no evaluation
+// (mcts.hpp:232-233: the reference returns the stored reward and goes straight to __backup), so with d.chain > 0 up
+// to that many such simulations are applied and followed by the next select inside the same round, until a leaf
+// that does need the evaluator has been issued.  The order of a tree's simulations is unchanged; only how many of
+// them fit between two evaluations is.
+__device__ __forceinline__ void az_round_body(const AzTreeDev& d, int phase_mask, int mode, int g, unsigned char* smem) {
+    int chained = 0;
+    for (;;) {
+        az_round_once(d, phase_mask, mode, g, smem);
+        if (phase_mask != 3 || d.L != 1 || chained >= d.chain) break;
+        __syncthreads();
+        if (uni(d.status[g]) != AZ_ST_RUN || uni(d.pending[g]) != AZ_PEND_TERMINAL) break;
+        ++chained;
+    }
+}
+
+// The per-game state table (some sixty pointers) is read from the kernel-argument segment where it is used, through
+// a pointer the compiler cannot see through: kept in registers across the loops of a round it costs more scalar
+// registers than a wave has (spilled to vector lanes, and those to memory in the 64-register pair kernel).
+typedef const __attribute__((address_space(4))) AzTreeDev* AzTreeArgs;
+#define AZ_TREE_ARGS(p_) ({ AzTreeArgs q_ = (p_); asm volatile("" : "+s"(q_)); (const AzTreeDev*)q_; })
+
 extern "C" __global__ void __launch_bounds__(AZ_WAVE)
-az_round_kernel(AzTreeDev d, int phase_mask, int mode, int g0) {
+az_round_kernel(AzTreeDev, int phase_mask, int mode, int g0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    az_round_body(d, phase_mask, mode, g0 + blockIdx.x, smem);         // a launch covers games [g0, g0 + gridDim.x)
+    const AzTreeDev* d = AZ_TREE_ARGS((AzTreeArgs)__builtin_amdgcn_kernarg_segment_ptr());
+    az_round_body(*d, phase_mask, mode, g0 + blockIdx.x, smem);        // a launch covers games [g0, g0 + gridDim.x)
 }
 
 // The tree half of the persistent pair (AzPairDev, az_dev.h): a wave takes its games in turn, round after round;
 // a game's step runs as soon as that game's evaluation is there, whatever the other games are doing.  Same
 // az_round_body as the lockstep kernel, so a game's tree is the same bit for bit: games share no tree state.
 extern "C" __global__ void __launch_bounds__(AZ_WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))
-az_round_pair_kernel(AzTreeDev d, AzPairDev pr, int mode) {
+az_round_pair_kernel(AzTreeDev, AzPairDev pr, int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AzTreeArgs ka = (AzTreeArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int G = ka->G;
     for (int i = 1; i <= pr.rounds; ++i) {
         const unsigned want = pr.base + (unsigned)i;
-        for (int g = blockIdx.x; g < d.G; g += gridDim.x) {
+        for (int g = blockIdx.x; g < G; g += gridDim.x) {
+            const AzTreeDev& d = *AZ_TREE_ARGS(ka);
             // the tree is never the hurry (its planes are wanted a whole tile later): poll seldom, stay out of the tower's way
             const bool ok = az_pair_wait<100>(pr.eval_seq + g, want, pr.abort, pr.timeout_ticks);
             if (__ballot(!ok) != 0ull) return;                          // a wait ran out somewhere: leave

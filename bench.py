@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--lockstep", action="store_true",
                     help="time the rounds as lockstep launches (evaluator, tree round, ...) instead of one launch of the "
                          "persistent tower / tree pair per step")
+    ap.add_argument("--chain", type=int, default=6,
+                    help="persistent pair only: simulations ending in a stored terminal leaf (which call no network, mcts.hpp:232-233) "
+                         "that a game may run back to back inside one round, so that the round's evaluation is not spent on a "
+                         "stale board (az_selfplay_chain); 0 = one simulation per game per round, as the lockstep launches")
     ap.add_argument("--no-lockstep-probe", action="store_true",
                     help="skip the second, informational measurement of the same games as lockstep launches")
     ap.add_argument("--full-games", type=float, default=40.0,
@@ -280,7 +284,7 @@ def main():
     else:
         blob = synth.make_blob(N, 3, Cs, 0)
 
-    def make_engines():
+    def make_engines(chain):
         es = [capi.Engine(N, K, G // NC, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0,
                           device=local_rank, game_slot_base=rank * G + i * (G // NC), precision=prec,
                           leaves_per_round=args.leaves) for i in range(NC)]
@@ -289,6 +293,8 @@ def main():
                 e.load_weights_dev(wt.data_ptr(), e.weights_size())
             else:
                 e.load_weights(blob)
+            if args.leaves == 1:
+                e.selfplay_chain(chain)
         return es
 
     # one step = one move's worth of rounds (sims/move descents per game, L per round)
@@ -298,10 +304,12 @@ def main():
     def agg(sts):
         return {k: sum(x[k] for x in sts) if k not in ("max_nodes", "max_edges") else max(x[k] for x in sts) for k in sts[0]}
 
-    def timed_leg(pair):
+    def timed_leg(pair, chain, steps):
         """warm-up + the timed region, either with every step as ONE launch of the persistent tower / tree pair
-        (az_selfplay_run_pair) or as lockstep launches (az_selfplay_run: evaluator, tree round, evaluator, ...)."""
-        es = make_engines()
+        (az_selfplay_run_pair) or as lockstep launches (az_selfplay_run: evaluator, tree round, evaluator, ...).
+        chain: simulations that end in a stored terminal leaf (no evaluation, mcts.hpp:232-233) a game may run back
+        to back inside one round (az_selfplay_chain)."""
+        es = make_engines(chain)
 
         def run(rounds):
             if pair:
@@ -349,16 +357,16 @@ def main():
         # HIP events around every `every`-th evaluator call and tree round of the timed region, within the
         # library's event pool (4096 spans): every launch when the region is short (every launch of the pair)
         spans_per_round = 3 if Cs[0] <= 128 and N <= 15 and prec != capi.AZ_PREC_FP16X3 else 2 * (len(Cs) - 1) + 2
-        every = 1 if pair else max(1, -(-(args.steps * rps * spans_per_round) // 3600))
+        every = 1 if pair else max(1, -(-(steps * rps * spans_per_round) // 3600))
         es[0].profile_enable(every)
         barrier()
         st0 = agg([e.stats() for e in es])
         t0 = time.perf_counter()
-        run(args.steps * rps)
+        run(steps * rps)
         barrier()
         el = time.perf_counter() - t0
         st = agg([e.stats() for e in es])
-        leg = {"pair": pair, "engs": es, "run": run, "el_local": el, "el": el, "every": every, "st": st,
+        leg = {"pair": pair, "chain": chain, "steps": steps, "engs": es, "run": run, "el_local": el, "el": el, "every": every, "st": st,
                "sims_local": st["sims_backed_up"] - st0["sims_backed_up"],
                "tally": {k: st[k] - st0[k] for k in TALLY},
                "prof": es[0].pair_read() if pair else es[0].profile_read(),
@@ -390,12 +398,12 @@ def main():
     probe.close()
     want_pair = fused_tower and NC == 1 and args.leaves == 1 and not args.lockstep and backend != "gloo"
     pair_fallback = None
-    leg = timed_leg(True) if want_pair else None
+    leg = timed_leg(True, args.chain, args.steps) if want_pair else None
     if leg is not None and "error" in leg:
         pair_fallback = leg["error"]
         leg = None
     if leg is None:
-        leg = timed_leg(False)
+        leg = timed_leg(False, 0, args.steps)
     engs, run, el, st = leg["engs"], leg["run"], leg["el"], leg["st"]
     sims_all, per_rank, prof, tally = leg["sims_all"], leg["per_rank"], leg["prof"], leg["tally"]
     fused, batch, every = leg["fused"], leg["batch"], leg["every"]
@@ -432,11 +440,18 @@ def main():
     # Informational second measurement, never `value`: the same games (same seeds, same number of timed rounds, same
     # device, same call) as lockstep launches.  It prices the tree round as a kernel of its own (`tree_roofline`)
     # and says what the persistent pair buys.
-    lock = None
+    lock = plain_pair = None
     if leg["pair"] and not args.no_lockstep_probe:
-        lock = timed_leg(False)
+        lock = timed_leg(False, 0, args.steps)
         for e in lock["engs"]:
             e.close()
+        if args.chain > 0:
+            # and the pair with one simulation per game per round, a third of the way between the two: what the
+            # overlap alone buys, without the chained terminal simulations
+            plain_pair = timed_leg(True, 0, min(args.steps, 8))
+            if "error" not in plain_pair:
+                for e in plain_pair["engs"]:
+                    e.close()
 
     if rank == 0:
         A = N * N
@@ -478,7 +493,7 @@ def main():
             if not (tl["descents"] > 0 and pf["tree_avg_us"] > 0):
                 return None
             tree_bytes = (12.0 * tl["children_scanned"] + 24.0 * tl["tree_levels"] + 16.0 * tl["children_expanded"]
-                          + tl["evals"] * (7.0 * A + 8.0)) / (args.steps * rps) / NC
+                          + tl["evals"] * (7.0 * A + 8.0)) / (lg["steps"] * rps) / NC
             tree_traffic = None
             if traffic is not None:
                 try:
@@ -498,8 +513,10 @@ def main():
                     "note": "a chain of dependent loads, one per tree level: latency-bound, 512 one-wave blocks"}
 
         if leg["pair"]:
-            step = ("one move of every game: %d rounds (%d sims/move, 1 per round) as ONE launch of the persistent tower / tree "
-                    "pair (az_tower_pair_kernel beside az_round_pair_kernel), re-root included" % (rps, budget))
+            step = ("%d rounds = %d evaluations per game, as ONE launch of the persistent tower / tree pair (az_tower_pair_kernel beside "
+                    "az_round_pair_kernel): a move's worth (%d sims/move) and, because up to %d simulations that end in a stored terminal leaf "
+                    "and call no network ride along in a round, %.3f simulations per game and round here; re-roots included"
+                    % (rps, rps, budget, leg["chain"], sims / (args.steps * rps * G * world)))
             roof = tower_roofline(prof["launch_avg_us"], prof["launches"], conv_flops * rps, "az_tower_pair_kernel",
                                   traffic * rps if traffic is not None else None)
             roof["rounds_per_launch"] = rps
@@ -520,7 +537,7 @@ def main():
                                    "(stem + 9 ResBlocks x 128 ch), vl=3 c_puct=3" % (N, N, G, budget),
                        "games_per_gpu": G, "sims_per_move": budget, "board": N, "parallelism": "games sharded x%d" % world,
                        "contexts_per_gpu": NC, "leaves_per_round": args.leaves,
-                       "rounds_as": "persistent pair" if leg["pair"] else "lockstep launches"},
+                       "rounds_as": "persistent pair" if leg["pair"] else "lockstep launches", "terminal_chain": leg["chain"]},
             "moves_per_s": sims / el / budget,
             "roofline": roof,
         }
@@ -538,11 +555,22 @@ def main():
             lp = lock["prof"]
             lr = tower_roofline(lp["conv_avg_us"], lp["conv_launches"], conv_flops, kernel, traffic)
             line["lockstep_launches"] = {
-                "value": lock["sims_all"] / lock["el"], "unit": "sims/s", "ms_per_round": lock["el"] / (args.steps * rps) * 1e3,
+                "value": lock["sims_all"] / lock["el"], "unit": "sims/s", "ms_per_round": lock["el"] / (lock["steps"] * rps) * 1e3,
+                "sims_per_game_round": lock["sims_all"] / (lock["steps"] * rps * G * world),
                 "pair_over_lockstep": (sims / el) / (lock["sims_all"] / lock["el"]),
                 "roofline": lr, "tree_round_avg_us": max(lp["tree_avg_us"] - lp["empty_span_us"], 0.0),
                 "note": "informational: the same games, seeds and number of timed rounds on the same device in the same call, every round "
                         "as two launches on one stream (az_tower_fused_kernel, az_round_kernel); `tree_roofline` is taken here"}
+        if plain_pair is not None:
+            if "error" in plain_pair:
+                line["pair_one_simulation_per_round"] = {"error": plain_pair["error"]}
+            else:
+                line["pair_one_simulation_per_round"] = {
+                    "value": plain_pair["sims_all"] / plain_pair["el"], "unit": "sims/s", "steps": plain_pair["steps"],
+                    "ms_per_round": plain_pair["el"] / (plain_pair["steps"] * rps) * 1e3,
+                    "note": "informational: the persistent pair with az_selfplay_chain(0); against lockstep_launches this is what hiding "
+                            "the tree work and the launch boundaries buys, the rest of the headline's margin is the terminal simulations "
+                            "that no longer cost an evaluation"}
         line["consistency"] = {"timed_region_s": el, "rounds_timed": args.steps * rps, "profile_every": every,
                                "sims_per_s_of_full_games_phase": games_info["sims_per_s"] if games_info else None}
         if per_rank is not None:

@@ -222,6 +222,15 @@ int az_tree_dump(az_ctx*, int game, int node_cap, int edge_cap, int32_t* n_nodes
  * game end attach rewards, restart).  Rows accumulate in a device ring. */
 int az_selfplay_begin(az_ctx*, int iter_budget);
 int az_selfplay_run(az_ctx*, int rounds);
+/* A simulation whose descent ends in a terminal leaf with a stored reward calls no network (mcts.hpp:232-233), but
+ * in a round of az_selfplay_run* every game owns one evaluation, used or not.  With max_chained > 0 a game runs up to
+ * that many such simulations back to back inside one round (backup, next select) until a leaf that needs the
+ * evaluator is out, so the evaluation of the round is not spent on a stale board.  The order of every tree's
+ * simulations, and with it every search result, move and row, is unchanged; what changes is how many simulations a
+ * round holds (az_stats.sims_backed_up grows faster than rounds x games).  0 (the default) = one simulation per game
+ * per round.  Needs leaves_per_round 1.  In lockstep rounds the tree launch lasts as long as its longest chain.
+ * AZ_CHAIN=k in the environment sets it at every az_selfplay_begin (for host programs that do not call this). */
+int az_selfplay_chain(az_ctx*, int max_chained);
 /* The same `rounds` rounds (generate.cpp:72-120; per search mcts.hpp:105-155) as ONE launch of two persistent
  * kernels that run side by side: the tower, one workgroup per CU walking its boards round after round, and the tree
  * waves, one per CU beside it.  A game's next evaluation starts as soon as that game's select has published its

@@ -15,9 +15,10 @@ def _rows_key(cells, tm, pol, rew):
     return sorted((cells[i].tobytes(), int(tm[i]), pol[i].tobytes(), rew[i].tobytes()) for i in range(len(tm)))
 
 
-def _engine(N, K, G, budget, seed=5):
+def _engine(N, K, G, budget, seed=5, chain=0):
     e = capi.Engine(N, K, G, Cs=synth.NETCONFIG2, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=seed)
     e.load_weights(synth.make_blob(N, 3, synth.NETCONFIG2, 0))
+    e.selfplay_chain(chain)
     e.selfplay_begin(budget)
     return e
 
@@ -31,9 +32,10 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("chain", [0, 5])
 @pytest.mark.parametrize("N,K,G,budget,rounds,chunks", CASES)
-def test_pair_plays_the_same_games_as_lockstep_rounds(N, K, G, budget, rounds, chunks):
-    a, b = _engine(N, K, G, budget), _engine(N, K, G, budget)
+def test_pair_plays_the_same_games_as_lockstep_rounds(N, K, G, budget, rounds, chunks, chain):
+    a, b = _engine(N, K, G, budget, chain=chain), _engine(N, K, G, budget, chain=chain)
     try:
         a.selfplay_run(rounds)
         a.sync()
@@ -125,3 +127,41 @@ def test_a_wait_that_runs_out_drains_both_kernels_and_is_reported():
             else:
                 os.environ[k] = v
         e.close()
+
+
+def test_chained_terminal_simulations_play_the_same_games_in_fewer_rounds():
+    """A simulation that ends in a stored terminal leaf needs no evaluation; run back to back inside a round
+    (az_selfplay_chain) such simulations change how many rounds a search takes, never what it finds: every game
+    the plain rounds finish is finished, row for row, by the chained rounds in the same number of rounds."""
+    N, K, G, budget, rounds = 5, 4, 37, 32, 600
+    a, b = _engine(N, K, G, budget, chain=0), _engine(N, K, G, budget, chain=6)
+    try:
+        a.selfplay_run(rounds)
+        b.selfplay_run(rounds)
+        a.sync()
+        b.sync()
+        sa, sb = a.stats(), b.stats()
+        assert sa["rounds"] == sb["rounds"] == rounds
+        assert sa["sims_backed_up"] <= rounds * G + G
+        assert sb["sims_backed_up"] > 1.05 * sa["sims_backed_up"]          # 5x5, four in a row: terminal leaves are common
+        assert sb["evals"] <= rounds * G + G and sb["games"] >= sa["games"] > 20
+        assert sa["error_games"] == sb["error_games"] == 0
+        ra, rb = _rows_key(*a.replay_drain()), _rows_key(*b.replay_drain())
+        assert len(ra) > 200
+        have = {}
+        for r in rb:
+            have[r] = have.get(r, 0) + 1
+        for r in ra:
+            assert have.get(r, 0) > 0, "a row of the plain rounds is missing from the chained rounds"
+            have[r] -= 1
+    finally:
+        a.close()
+        b.close()
+
+
+def test_chain_needs_one_leaf_per_round():
+    e = capi.Engine(9, 5, 8, eval_mode=capi.AZ_EVAL_HASH, max_budget=16, leaves_per_round=2)
+    with pytest.raises(capi.AzError, match="leaves_per_round"):
+        e.selfplay_chain(3)
+    e.selfplay_chain(0)
+    e.close()
