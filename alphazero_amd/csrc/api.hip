@@ -59,6 +59,9 @@ struct az_ctx {
     bool have_weights = false;
     unsigned short *actX = nullptr, *actH = nullptr;      // per-layer path: [rows][C_pad] 16-bit inputs of the convolutions
     float* actR = nullptr;                                // per-layer path: [rows][C_pad] fp32 residual stream
+    unsigned short* actL = nullptr;                       // per-layer path, default kernel: the stream as actX + actL (16-bit remainder);
+                                                          // actR then holds only the last block's output, for the heads
+    bool hilo = false;
     size_t act_rows = 0;
     float *stem_w = nullptr, *stem_b = nullptr;           // [C_pad][27], [C_pad]
     unsigned short* stem_wbf = nullptr;                   // [128][32] bf16, fused path
@@ -293,6 +296,13 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
             AZCHK(dalloc(c, &c->actX, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->actH, c->act_rows * c->C_pad));
             AZCHK(dalloc(c, &c->actR, c->act_rows * c->C_pad));
+            // The residual stream between the blocks as a pair of 16-bit images (the 16-bit copy the next convolution
+            // reads anyway + the remainder): 8 instead of 10 bytes per element through HBM in a block's second
+            // convolution, which is HBM-bound at 128 channels.  The default per-layer kernel only; AZ_NO_HILO keeps
+            // the fp32 image between the blocks too (A/B).
+            // At 256 channels that convolution is MFMA-bound and the pair buys nothing (AZ_HILO=1 forces it for the A/B).
+            c->hilo = c->conv_kind == 0 && !c->split && !getenv("AZ_NO_HILO") && (c->C_pad == 128 || getenv("AZ_HILO"));
+            if (c->hilo) AZCHK(dalloc(c, &c->actL, c->act_rows * c->C_pad));
             if (az_tower_heads_lds_bytes(N, c->C_pad, c->c_out) > 128 * 1024 || az_tower_stem_lds_bytes(N, c->C_pad, c->c_in) > 64 * 1024)
                 return fail(AZ_E_ARG, "tower heads do not fit LDS: c_out %d x %d channels, c_in %d", c->c_out, c->C_pad, c->c_in);
             AZCHK(dalloc(c, &c->stem_w, (size_t)c->C_pad * c->c_in * 9));
@@ -456,7 +466,8 @@ extern "C" int az_weights_info_get(const az_ctx* c, az_weights_info* out) {
 // block's second convolution updates in place and the heads read; unused by the fused kernel, whose
 // activations never leave LDS and registers.
 static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev, float* val_dev,
-                        unsigned short* actX, unsigned short* actH, float* actR, bool sampled, const unsigned* mask = nullptr) {
+                        unsigned short* actX, unsigned short* actH, float* actR, unsigned short* actL, bool sampled,
+                        const unsigned* mask = nullptr) {
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled, c->stream);
@@ -466,7 +477,7 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         HIPCHK(hipGetLastError());
         return AZ_OK;
     }
-    az_launch_stem(c->stream, c->prec, planes_dev, actX, actR, c->stem_w, c->stem_b, B, N, Cp, Gd, c->c_in);
+    az_launch_stem(c->stream, c->prec, planes_dev, actX, actR, c->hilo ? actL : nullptr, c->stem_w, c->stem_b, B, N, Cp, Gd, c->c_in);
     if (c->split) {
         // AZ_PREC_FP16X3.  Every operand is a pair hi + lo of fp16 values; conv(W, x) = W_hi x_hi + W_hi x_lo + W_lo x_hi
         // as ONE reduction over three times the channels (activation rows [hi | lo | hi], weight image [W_hi | W_hi |
@@ -482,11 +493,11 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
             const float* b1 = c->conv_b + (size_t)(2 * i) * Cp;
             HIPCHK(hipMemsetAsync(c->actS + body, 0, M_pad * Cp * 4, c->stream));
             bool on = prof_begin(c, 0, sampled, c->stream);
-            az_launch_conv3x3(c->stream, c->prec, 0, c->catX, actH, c->actS, w1, b1, Cp, M, N, Gd, 1, 3 * Cp);
+            az_launch_conv3x3(c->stream, c->prec, 0, c->catX, actH, c->actS, nullptr, w1, b1, Cp, M, N, Gd, 1, 3 * Cp);
             prof_end(c, on, c->stream);
             az_launch_cat3(c->stream, c->prec, c->actS + body, c->catH + 3 * body, M_pad, Cp);
             on = prof_begin(c, 0, sampled, c->stream);
-            az_launch_conv3x3(c->stream, c->prec, 0, c->catH, actX, actR, w2, b1 + Cp, Cp, M, N, Gd, 1, 3 * Cp);
+            az_launch_conv3x3(c->stream, c->prec, 0, c->catH, actX, actR, nullptr, w2, b1 + Cp, Cp, M, N, Gd, 1, 3 * Cp);
             prof_end(c, on, c->stream);
             az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
         }
@@ -498,10 +509,12 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
         const unsigned short* w1 = c->conv_w + (size_t)(2 * i) * c->conv_layer_elems;
         const unsigned short* w2 = c->conv_w + (size_t)(2 * i + 1) * c->conv_layer_elems;
         bool on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actX, actH, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1, 0);
+        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actX, actH, nullptr, nullptr, w1, c->conv_b + (size_t)(2 * i) * Cp, Cp, M, N, Gd, 1, 0);
         prof_end(c, on, c->stream);
         on = prof_begin(c, 0, sampled, c->stream);
-        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actH, actX, actR, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1, 0);
+        // the stream stays a 16-bit pair from block to block; the last block leaves it in fp32 for the heads
+        az_launch_conv3x3(c->stream, c->prec, c->conv_kind, actH, actX, c->hilo && i + 1 < c->num_res ? nullptr : actR,
+                          c->hilo ? actL : nullptr, w2, c->conv_b + (size_t)(2 * i + 1) * Cp, Cp, M, N, Gd, 1, 0);
         prof_end(c, on, c->stream);
     }
     az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat, mask);
@@ -513,7 +526,7 @@ static int tower_run(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_dev
     if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
     if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
     const bool sampled = c->prof_every > 0 && (c->prof_calls++ % c->prof_every) == 0;
-    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, c->actR, sampled, mask);
+    return tower_launch(c, planes_dev, B, pol_dev, val_dev, c->actX, c->actH, c->actR, c->actL, sampled, mask);
 }
 
 extern "C" int az_tower_forward_dev(az_ctx* c, const uint8_t* boards_dev, int B, float* policy_dev, float* value_dev) {
@@ -558,7 +571,7 @@ extern "C" size_t az_tower_static_max_batch(const az_ctx* c) {
     if (c->fused) return (size_t)c->Bmax;                    // the fused kernel has no scratch: the context's own limit
     // the array holds three images of the same rows: two 16-bit ones (a quarter each) and the fp32 one (a half)
     const size_t row = (size_t)c->C_pad * 2, fixed = 2 * (size_t)c->Gd + 255;   // guard rows + round-up to a 256-row tile
-    const size_t rows = AZ_STATIC_SCRATCH_BYTES / 4 / row;
+    const size_t rows = AZ_STATIC_SCRATCH_BYTES / (c->hilo ? 5 : 4) / row;      // two 16-bit images + fp32 (+ the 16-bit remainder)
     return rows > fixed ? (rows - fixed) / (size_t)c->P : 0;
 }
 
@@ -570,7 +583,7 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
     HIPCHK(hipSetDevice(c->cfg.device));
     if (c->fused) {                                          // activations stay in LDS: nothing to place
         if (B < 1 || B > c->Bmax) return fail(AZ_E_ARG, "batch %d out of range (1..%d)", B, c->Bmax);
-        return tower_launch(c, boards_dev, B, policy_dev, value_dev, nullptr, nullptr, nullptr, false);
+        return tower_launch(c, boards_dev, B, policy_dev, value_dev, nullptr, nullptr, nullptr, nullptr, false);
     }
     unsigned char* const base = c->cfg.device < AZ_MAX_DEVICES ? g_scratch_ptr[c->cfg.device] : nullptr;
     if (!base) return fail(AZ_E_STATE, "static scratch of device %d was not set up", c->cfg.device);
@@ -589,13 +602,17 @@ extern "C" int az_tower_forward_static(az_ctx* c, const uint8_t* boards_dev, int
     }
     const size_t row = (size_t)c->C_pad * 2;
     const size_t M = (size_t)B * c->P, M_pad = (M + 255) / 256 * 256, rows = M_pad + 2 * (size_t)c->Gd;
-    unsigned char* const img[3] = {base, base + AZ_STATIC_SCRATCH_BYTES / 4, base + AZ_STATIC_SCRATCH_BYTES / 2};
-    for (int k = 0; k < 3; ++k) {
+    // the array in equal parts: 16-bit image, 16-bit image, fp32 image (two parts), and the 16-bit remainder of the
+    // stream where the context keeps it as a pair
+    const size_t part = (AZ_STATIC_SCRATCH_BYTES / (c->hilo ? 5 : 4)) & ~(size_t)255;
+    unsigned char* const img[4] = {base, base + part, base + 2 * part, base + 4 * part};
+    for (int k = 0; k < (c->hilo ? 4 : 3); ++k) {
         const size_t rb = k == 2 ? 2 * row : row;            // bytes per row: 16-bit images, fp32 residual stream
         HIPCHK(hipMemsetAsync(img[k], 0, (size_t)c->Gd * rb, c->stream));
         HIPCHK(hipMemsetAsync(img[k] + ((size_t)c->Gd + M) * rb, 0, (rows - c->Gd - M) * rb, c->stream));
     }
-    return tower_launch(c, boards_dev, B, policy_dev, value_dev, (unsigned short*)img[0], (unsigned short*)img[1], (float*)img[2], false);
+    return tower_launch(c, boards_dev, B, policy_dev, value_dev, (unsigned short*)img[0], (unsigned short*)img[1], (float*)img[2],
+                        c->hilo ? (unsigned short*)img[3] : nullptr, false);
 }
 
 // --------------------------------------------------------------------- env

@@ -9,11 +9,14 @@ extern "C" {
 int  az_tower_configure(void);
 size_t az_tower_fused_lds_bytes(int N, int n_layers, int rows);   // dynamic LDS of az_tower_fused_kernel
 
-void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
-                    const float* bias, int B, int N, int C_pad, int Gd, int c_in);
+// out_lo non-null: the residual stream leaves as the pair out + out_lo of 16-bit images instead of the fp32 image out32
+void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, unsigned short* out_lo,
+                    const float* w, const float* bias, int B, int N, int C_pad, int Gd, int c_in);
 int  az_conv_kind(void);                                          // per-layer convolution kernel (0, 1, 2), from the environment
+// resid / lo (a ResBlock's second convolution): resid alone = the fp32 residual stream, updated in place; lo alone
+// (kind 0 only) = the stream as the pair out + lo, both updated in place; both = the pair in, resid (fp32) out
 void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
-                       float* resid, const unsigned short* wpk, const float* bias,
+                       float* resid, unsigned short* lo, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu, int Cin /* channels of `in`, 0 = C_pad (kind 0 only) */);
 void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                            const float* stem_b, const unsigned short* wpk, const float* bias,

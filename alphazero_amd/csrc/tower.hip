@@ -90,11 +90,18 @@ template <> struct Prec<1> {
     }
 };
 
+// The residual stream as a pair of 16-bit values: x = hi + lo / AZ_LO_SCALE, hi = x rounded to the operand format
+// (the copy the next convolution reads), lo = the remainder x - hi (exact in fp32), scaled by 2^11 before it is
+// rounded: unscaled, the remainder of an activation below 0.125 is a subnormal fp16 number and keeps few or no bits.
+#define AZ_LO_SCALE 2048.0f
+#define AZ_LO_INV (1.0f / 2048.0f)
+
 // ------------------------------------------------------------------- stem
 // One block per board.  w: [C_pad][27] fp32 (BN folded), bias [C_pad].
 template <int PR>
 __global__ void __launch_bounds__(256)
 az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out, float* __restrict__ out32,
+               unsigned short* __restrict__ out_lo /* non-null: the stream as out + out_lo (16-bit pair) instead of out32 */,
                const float* __restrict__ w, const float* __restrict__ bias,
                int N, int C_pad, int Gd, int c_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -130,7 +137,12 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
         }
         const unsigned pk = (unsigned)Prec<PR>::to16(a0) | ((unsigned)Prec<PR>::to16(a1) << 16);
         *(unsigned*)(out + ((size_t)(Gd + b * P + p)) * C_pad + c) = pk;
-        *(float2*)(out32 + ((size_t)(Gd + b * P + p)) * C_pad + c) = make_float2(a0, a1);     // the residual stream stays fp32
+        if (out_lo)                                                                           // the stream = this 16-bit copy + a 16-bit remainder
+            *(unsigned*)(out_lo + ((size_t)(Gd + b * P + p)) * C_pad + c) =
+                (unsigned)Prec<PR>::to16((a0 - Prec<PR>::from16((unsigned short)pk)) * AZ_LO_SCALE) |
+                ((unsigned)Prec<PR>::to16((a1 - Prec<PR>::from16((unsigned short)(pk >> 16))) * AZ_LO_SCALE) << 16);
+        else
+            *(float2*)(out32 + ((size_t)(Gd + b * P + p)) * C_pad + c) = make_float2(a0, a1); // the residual stream stays fp32
     }
 }
 
@@ -142,6 +154,7 @@ az_stem_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ 
 template <int PR, int CIN>
 __global__ void __launch_bounds__(256)
 az_stem_mfma_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out, float* __restrict__ out32,
+                    unsigned short* __restrict__ out_lo /* non-null: the stream as out + out_lo instead of out32 */,
                     const float* __restrict__ w, const float* __restrict__ bias, int N, int C_pad, int Gd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((ext_vector_type(16))) float f32x16s;
@@ -205,7 +218,15 @@ az_stem_mfma_kernel(const uint8_t* __restrict__ planes, unsigned short* __restri
                         pk.x = (unsigned)Prec<PR>::to16(o.x) | ((unsigned)Prec<PR>::to16(o.y) << 16);
                         pk.y = (unsigned)Prec<PR>::to16(o.z) | ((unsigned)Prec<PR>::to16(o.w) << 16);
                         *(uint2*)(out + orow + 32 * m + 8 * q) = pk;
-                        *(float4*)(out32 + orow + 32 * m + 8 * q) = o;     // the residual stream stays fp32
+                        if (out_lo) {                                       // the stream = this 16-bit copy + a 16-bit remainder
+                            uint2 lo;
+                            lo.x = (unsigned)Prec<PR>::to16((o.x - Prec<PR>::from16((unsigned short)pk.x)) * AZ_LO_SCALE) |
+                                   ((unsigned)Prec<PR>::to16((o.y - Prec<PR>::from16((unsigned short)(pk.x >> 16))) * AZ_LO_SCALE) << 16);
+                            lo.y = (unsigned)Prec<PR>::to16((o.z - Prec<PR>::from16((unsigned short)pk.y)) * AZ_LO_SCALE) |
+                                   ((unsigned)Prec<PR>::to16((o.w - Prec<PR>::from16((unsigned short)(pk.y >> 16))) * AZ_LO_SCALE) << 16);
+                            *(uint2*)(out_lo + orow + 32 * m + 8 * q) = lo;
+                        } else
+                            *(float4*)(out32 + orow + 32 * m + 8 * q) = o;  // the residual stream stays fp32
                     }
             }
         }
@@ -679,13 +700,18 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& 
 // (AzFoldArgs::layer16: row 16 a + l of a 128-channel block holds channel 64 (a >> 2) + 4 l + (a & 3)).  In that
 // layout a lane holds four consecutive channels of a position and a 16-lane MFMA row 64 of them, so the outputs go
 // from the accumulators to HBM in whole cache lines; LDS is used in the epilogue only to bring the residual in.
-// RESID: second convolution of a ResBlock (resid = the fp32 residual stream, updated in place); RELU: network.hpp:33,36.
-// Both are template parameters so that the epilogue is straight-line code (as run-time flags they cost three
-// branches and both conversions per four values).
-template <int PR, bool RESID, bool RELU>
+// RM: 0 = first convolution of a ResBlock; otherwise its second (x = relu(conv + bias + x), network.hpp:36) and how the
+// residual stream x is kept: 1 = one fp32 image (resid), updated in place; 2 = a pair of 16-bit images hi + lo, hi =
+// the 16-bit image the next convolution reads anyway (`out`, read here before it is overwritten), lo = the rounding
+// remainder x - hi, scaled (`lo`, updated in place; AZ_LO_SCALE): 22 significant bits in fp16, and 8 bytes per element through HBM
+// instead of 10; 3 = hi + lo in, fp32 out (the last block: the heads read resid).  RELU: network.hpp:33,36.
+// Template parameters so that the epilogue is straight-line code (as run-time flags they cost three branches and
+// both conversions per four values).
+template <int PR, int RM, bool RELU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
-                       float* resid /* RESID: the fp32 residual stream, else unused */, const unsigned short* __restrict__ wpk,
+az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* out,
+                       float* resid /* RM 1: the fp32 stream, in and out; RM 3: out */, unsigned short* lo /* RM 2, 3 */,
+                       const unsigned short* __restrict__ wpk,
                        const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int xcd_tiles,
                        int Cin /* channels (and row pitch) of `in` = the reduction's extent; C_pad except in the compensated mode */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -757,9 +783,12 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
     // -- no address registers per access.
     const size_t tile0 = (size_t)(Gd + m0) * C_pad + nb * 128;
     const unsigned lane0 = (unsigned)((64 * wv + 4 * gc) * C_pad + 4 * lrc);                 // in elements
+    constexpr bool RESID = RM == 1, HILO = RM >= 2;
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(RESID ? resid + tile0 : (float*)nullptr), 0, RESID ? T4_M * C_pad * 4 : 0, 0x00020000);
+        (void*)((RM == 1 || RM == 3) ? resid + tile0 : (float*)nullptr), 0, (RM == 1 || RM == 3) ? T4_M * C_pad * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + tile0), 0, T4_M * C_pad * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(HILO ? lo + tile0 : (unsigned short*)nullptr), 0, HILO ? T4_M * C_pad * 2 : 0, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const float4 bv = *(const float4*)(bias + nb * 128 + 64 * q + 4 * lrc);              // channels 64 q + 4 lrc .. + 3
@@ -899,14 +928,49 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
 #define RES_DMA(p_) do { _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_)      /* DMA q: image rows 2q, 2q + 1 */ \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_void*)(img + q_ * 1024), 16, dma_voff, \
                                                  (64 * wvu + 32 * (p_) + 2 * q_) * C_pad * 4, 0, 0); } while (0)
+    // hi + lo stream: the same two passes, a wave's 32 rows of both 16-bit images ([32][128] x 2 B each, hi then lo)
+    // in the 16 KB the fp32 image takes; one DMA = four image rows
+    const unsigned dma16_voff = (unsigned)((lane >> 4) * C_pad * 2 + (lane & 15) * 16);
+#define RES_DMA16(p_) do { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) { \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ors, (lds_void*)(img + q_ * 1024), 16, dma16_voff, \
+                                                 (64 * wvu + 32 * (p_) + 4 * q_) * C_pad * 2, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void*)(img + 8192 + q_ * 1024), 16, dma16_voff, \
+                                                 (64 * wvu + 32 * (p_) + 4 * q_) * C_pad * 2, 0, 0); } } while (0)
     if constexpr (RESID) {
         __syncthreads();                                                     // all waves done with the buffers
         RES_DMA(0);
+    }
+    if constexpr (HILO) {
+        __syncthreads();
+        RES_DMA16(0);
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const unsigned rmask = (unsigned)(realmask >> (32 * p));                             // rows 32 p .. 32 p + 31 of the wave
         float4 rv[2][2][4];
+        if constexpr (HILO) {
+            AZ_DMA_LANDED();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned char* at = img + (16 * bb + 4 * gc + r) * 256 + 128 * q + 8 * lrc;
+                        const uint2 h = *(const uint2*)at, l = *(const uint2*)(at + 8192);
+                        rv[q][bb][r] = make_float4(
+                            fmaf(Prec<PR>::from16((unsigned short)l.x), AZ_LO_INV, Prec<PR>::from16((unsigned short)h.x)),
+                            fmaf(Prec<PR>::from16((unsigned short)(l.x >> 16)), AZ_LO_INV, Prec<PR>::from16((unsigned short)(h.x >> 16))),
+                            fmaf(Prec<PR>::from16((unsigned short)l.y), AZ_LO_INV, Prec<PR>::from16((unsigned short)h.y)),
+                            fmaf(Prec<PR>::from16((unsigned short)(l.y >> 16)), AZ_LO_INV, Prec<PR>::from16((unsigned short)(h.y >> 16))));
+                    }
+            if (p == 0) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);                          // the images are in registers (lgkmcnt 0)
+                __builtin_amdgcn_sched_barrier(0);
+                RES_DMA16(1);
+            }
+        }
         if constexpr (RESID) {
             AZ_DMA_LANDED();
             __builtin_amdgcn_sched_barrier(0);
@@ -934,7 +998,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
                 for (int q = 0; q < 2; ++q) {
                     const int so = (16 * b + r) * C_pad + 64 * q;                            // scalar: row and channel half
                     float v0 = acc[4 * q][b][r], v1 = acc[4 * q + 1][b][r], v2 = acc[4 * q + 2][b][r], v3 = acc[4 * q + 3][b][r];
-                    if constexpr (RESID) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
+                    if constexpr (RM != 0) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
                     uint2 o;
                     if constexpr (RELU) {
                         v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap);
@@ -944,14 +1008,23 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* _
                         o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
                         o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                     }
-                    if constexpr (RESID)
+                    if constexpr (RM == 1 || RM == 3)
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)},
                                                                rrs, lane0 * 4, so * 4, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, ors, lane0 * 2, so * 2, 0);
+                    if constexpr (RM == 2) {                                 // what the 16-bit copy drops, as a second 16-bit value
+                        const unsigned l0 = Prec<PR>::pack2((v0 - Prec<PR>::from16((unsigned short)o.x)) * AZ_LO_SCALE,
+                                                            (v1 - Prec<PR>::from16((unsigned short)(o.x >> 16))) * AZ_LO_SCALE);
+                        const unsigned l1 = Prec<PR>::pack2((v2 - Prec<PR>::from16((unsigned short)o.y)) * AZ_LO_SCALE,
+                                                            (v3 - Prec<PR>::from16((unsigned short)(o.y >> 16))) * AZ_LO_SCALE);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, lrs, lane0 * 2, so * 2, 0);
+                    }
+                    if constexpr (RM != 3)                                   // (the last block's output feeds the heads only)
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, ors, lane0 * 2, so * 2, 0);
                 }
             }
     }
 #undef RES_DMA
+#undef RES_DMA16
 }
 
 // ------------------------------------------------------------ fused tower
@@ -1897,7 +1970,8 @@ extern "C" int az_tower_configure(void) {
 #define SETA(k, bytes) do { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); } while (0)
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
-#define SETA4(pr) SETA((az_conv3x3_t256s_kernel<pr, false, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, true, true>), 80 * 1024)
+#define SETA4(pr) SETA((az_conv3x3_t256s_kernel<pr, 0, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, 1, true>), 80 * 1024); \
+                  SETA((az_conv3x3_t256s_kernel<pr, 2, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, 3, true>), 80 * 1024)
     SETA4(0); SETA4(1);
 #undef SETA4
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
@@ -1913,19 +1987,19 @@ extern "C" int az_tower_configure(void) {
 // prec: 0 = bf16 operands, 1 = fp16 operands
 #define BY_PREC(kern, ...) do { if (prec == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
 
-extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32, const float* w,
-                               const float* bias, int B, int N, int C_pad, int Gd, int c_in) {
+extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, unsigned short* out, float* out32,
+                               unsigned short* out_lo, const float* w, const float* bias, int B, int N, int C_pad, int Gd, int c_in) {
     // the planes the two games here use run on the fp32 MFMA form; any other count on the generic kernel
     if (c_in == 3 || c_in == 5) {
         const size_t smm = (size_t)c_in * N * N + 16 + (size_t)C_pad * 4;
-#define STEM_MFMA(PR_, CIN_) hipLaunchKernelGGL((az_stem_mfma_kernel<PR_, CIN_>), dim3(B), dim3(256), smm, s, planes, out, out32, w, bias, N, C_pad, Gd)
+#define STEM_MFMA(PR_, CIN_) hipLaunchKernelGGL((az_stem_mfma_kernel<PR_, CIN_>), dim3(B), dim3(256), smm, s, planes, out, out32, out_lo, w, bias, N, C_pad, Gd)
         if (prec == 1) { if (c_in == 3) STEM_MFMA(1, 3); else STEM_MFMA(1, 5); }
         else { if (c_in == 3) STEM_MFMA(0, 3); else STEM_MFMA(0, 5); }
 #undef STEM_MFMA
         return;
     }
     const size_t sm = (size_t)C_pad * (c_in * 9 + 1) * 4 + (size_t)c_in * N * N + 16;
-    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, w, bias, N, C_pad, Gd, c_in);
+    BY_PREC(az_stem_kernel, dim3(B), dim3(256), sm, s, planes, out, out32, out_lo, w, bias, N, C_pad, Gd, c_in);
 }
 
 // Which per-layer convolution kernel a tower uses; read once when the tower is created, because the order of the
@@ -1938,7 +2012,7 @@ extern "C" int az_conv_kind(void) {
 }
 
 extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
-                                  float* resid, const unsigned short* wpk, const float* bias,
+                                  float* resid, unsigned short* lo, const unsigned short* wpk, const float* bias,
                                   int C_pad, int M, int N, int Gd, int relu, int Cin) {
     if (Cin <= 0) Cin = C_pad;                                           // the kernels of kinds 1 and 2 take square layers only
     if (kind != 2) {                                                      // 256 rows x 128 channels, two workgroups per CU
@@ -1950,10 +2024,12 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsig
         const dim3 grid = plain ? dim3(tiles, C_pad / 128) : dim3(8 * xcd_tiles * (C_pad / 128));
         if (kind == 0) {
 #define T4S_GO(pr, rs, rl) hipLaunchKernelGGL((az_conv3x3_t256s_kernel<pr, rs, rl>), grid, dim3(256), sm, s, \
-                                              in, out, resid, wpk, bias, C_pad, M, tiles, N, Gd, xcd_tiles, Cin)
+                                              in, out, resid, lo, wpk, bias, C_pad, M, tiles, N, Gd, xcd_tiles, Cin)
             // every 3x3 convolution of the tower is followed by a ReLU (network.hpp:33,36): the forms without one are
             // not instantiated (relu is ignored here; the other two kernels take it at run time)
-#define T4S_BY_FLAGS(pr) do { if (resid) T4S_GO(pr, true, true); else T4S_GO(pr, false, true); } while (0)
+            // residual stream: none (a block's first convolution), fp32 in place, hi + lo in place, hi + lo in and fp32 out
+#define T4S_BY_FLAGS(pr) do { if (lo && resid) T4S_GO(pr, 3, true); else if (lo) T4S_GO(pr, 2, true); \
+                              else if (resid) T4S_GO(pr, 1, true); else T4S_GO(pr, 0, true); } while (0)
             if (prec == 1) T4S_BY_FLAGS(1); else T4S_BY_FLAGS(0);
 #undef T4S_BY_FLAGS
 #undef T4S_GO

@@ -102,7 +102,7 @@ def test_static_scratch_is_one_per_gpu_and_says_so():
     """Two contexts on one GPU share the array: a call while the other context's call is still running is refused
     with AZ_E_STATE instead of overwriting its activations; once that context has drained the call goes through."""
     import torch
-    N, Cs, B = 19, synth.NETCONFIG2, 150
+    N, Cs, B = 19, synth.NETCONFIG2, 120
     a = capi.Engine(N, 5, B, Cs=Cs)
     b = capi.Engine(N, 5, 4, Cs=Cs)
     blob = synth.make_blob(N, 3, Cs, 98)
@@ -114,7 +114,7 @@ def test_static_scratch_is_one_per_gpu_and_says_so():
     pb, vb = torch.empty((4, a.A), device="cuda"), torch.empty((4, 2), device="cuda")
     torch.cuda.synchronize()
     refused = 0
-    for _ in range(3):                                     # a 150-board forward takes milliseconds; the next call comes microseconds later
+    for _ in range(3):                                     # a 120-board forward takes milliseconds; the next call comes microseconds later
         a.tower_forward_static(big.data_ptr(), B, pa.data_ptr(), va.data_ptr())
         try:
             b.tower_forward_static(small.data_ptr(), 4, pb.data_ptr(), vb.data_ptr())
