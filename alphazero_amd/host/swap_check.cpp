@@ -1,8 +1,8 @@
 // swap_check.cpp -- the trainer -> generator weight hand-off (util.h:60-139, generate.cpp:73) against a
 // running self-play: ckpt_location.txt is rewritten under flock(LOCK_EX) as save_network does, the
 // generator's load() notices, the blob goes through az_group_load_weights (RCCL broadcast + device-side
-// fold) and the network that answers changes between two rounds.  Also: a pointer to a libtorch archive
-// whose .azw twin does not exist yet keeps the current weights instead of ending the process.
+// fold) and the network that answers changes between two rounds.  Also: a pointer to a file that is neither a blob
+// nor a readable libtorch archive (a checkpoint cut short) keeps the current weights instead of ending the process.
 //   usage: swap_check <contexts_per_gpu>      (run in an empty directory)
 #include <sys/file.h>
 #include <unistd.h>
@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     B.blob = az::fresh_blob(Env::N, 3, Cs, 2);
     az::write_azw("model_1.pt.azw", A);
     az::write_azw("model_2.pt.azw", B);
-    { std::ofstream f("model_3.pt", std::ios::binary); f << "PK\x03\x04 not a blob"; }      // an archive without its twin
+    { std::ofstream f("model_3.pt", std::ios::binary); f << "PK\x03\x04 not a blob"; }      // starts like an archive, is none
     point_at("model_1.pt");
 
     az::SelfPlay<Env> agent(32, 16, 3, 3, 0, 7, 0, contexts);
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     const std::vector<float> a0 = answer(first, x), a1 = answer(last, x);
     REQUIRE(a0 == a1);
     REQUIRE(!agent.load());                                      // pointer unchanged
-    point_at("model_3.pt");                                      // trainer published an archive; no .azw yet
+    point_at("model_3.pt");                                      // an unreadable checkpoint
     REQUIRE(!agent.load());
     REQUIRE(agent.model() == "model_1.pt");
     agent.run(16);

@@ -1,8 +1,9 @@
 // util.hpp -- the checkpoint pointer protocol of util.h:60-139 for the flat
 // weight blob the HIP tower consumes.  `ckpt_location.txt` (read under
 // flock(LOCK_SH), util.h:63-87) names the newest `<prefix>_<ver>.pt`; the blob
-// is looked up as `<that path>.azw` (written by tools/pt2blob.py from the
-// libtorch archive) or, if the named file itself is a blob, read directly.
+// is looked up as `<that path>.azw` (a converted twin, tools/pt2blob.py), or the
+// named file is read directly: as a blob, or as the trainer's own libtorch
+// archive (`torch::save(net, path)`, util.h:108-139; ptarchive.hpp, no libtorch).
 #pragma once
 #include <sys/file.h>
 #include <unistd.h>
@@ -19,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "ptarchive.hpp"
 #include "tensor.hpp"
 
 namespace az {
@@ -53,6 +55,48 @@ inline void write_azw(const std::string& path, const WeightFile& w) {
     const uint64_t n = w.blob.size();
     f.write((const char*)&n, 8);
     f.write((const char*)w.blob.data(), (std::streamsize)(n * 4));
+}
+
+// The trainer's checkpoint (torch::save(net, path), util.h:125) -> blob: tensors by their registered names
+// (network.hpp:106-114: CBlock, PHead, VHead, RBlock_i; running_mean / running_var are buffers of the BatchNorms),
+// in the blob's order; the tower's shape is read off the tensors.  Throws pt::Error if the file is not such an archive.
+inline void read_pt(const std::string& path, WeightFile& w) {
+    pt::Archive a(path);
+    auto shape = [&](const std::string& n) -> const std::vector<int64_t>& { return a.at(n).shape; };
+    if (shape("CBlock.conv.weight").size() != 4 || shape("VHead.fc1.weight").size() != 2)
+        throw pt::Error(path + ": CBlock.conv.weight / VHead.fc1.weight do not have a convolution's / a linear layer's shape");
+    w.Cs.clear();
+    w.Cs.push_back((int)shape("CBlock.conv.weight")[0]);
+    w.c_in = (int)shape("CBlock.conv.weight")[1];
+    for (int i = 0; a.has("RBlock_" + std::to_string(i) + ".conv1.weight"); ++i)
+        w.Cs.push_back((int)shape("RBlock_" + std::to_string(i) + ".conv1.weight")[0]);
+    w.c_out = (int)shape("PHead.conv.weight")[0];
+    const int A = (int)shape("VHead.fc1.weight")[1];
+    w.N = (int)std::lround(std::sqrt((double)A));
+    if (w.N * w.N != A || w.Cs.size() < 2) throw pt::Error(path + ": not a PVNetwork checkpoint (fc1 width / ResBlocks)");
+    w.blob.clear();
+    auto put = [&](const std::string& n, std::vector<int64_t> want) {
+        const pt::Tensor& t = a.at(n);
+        if (t.shape != want) throw pt::Error(path + ": tensor " + n + " has an unexpected shape");
+        w.blob.insert(w.blob.end(), t.v.begin(), t.v.end());
+    };
+    auto conv = [&](const std::string& m, int64_t ci, int64_t co, int64_t k) { put(m + ".weight", {co, ci, k, k}); put(m + ".bias", {co}); };
+    auto bn = [&](const std::string& m, int64_t ch) {
+        put(m + ".weight", {ch}); put(m + ".bias", {ch}); put(m + ".running_mean", {ch}); put(m + ".running_var", {ch});
+    };
+    const size_t num_res = w.Cs.size() - 1;
+    const int64_t Ch = w.Cs[num_res - 1];
+    conv("CBlock.conv", w.c_in, w.Cs[0], 3); bn("CBlock.bn", w.Cs[0]);
+    conv("PHead.conv", Ch, w.c_out, 1);
+    conv("VHead.conv", Ch, 1, 1); bn("VHead.bn", 1);
+    const int64_t vd = shape("VHead.fc2.weight").empty() ? 2 : shape("VHead.fc2.weight")[0];
+    put("VHead.fc1.weight", {64, A}); put("VHead.fc1.bias", {64});
+    put("VHead.fc2.weight", {vd, 64}); put("VHead.fc2.bias", {vd});
+    for (size_t i = 0; i < num_res; ++i) {
+        const std::string r = "RBlock_" + std::to_string(i);
+        conv(r + ".conv1", w.Cs[i], w.Cs[i + 1], 3); conv(r + ".conv2", w.Cs[i + 1], w.Cs[i + 1], 3);
+        bn(r + ".bn1", w.Cs[i + 1]); bn(r + ".bn2", w.Cs[i + 1]);
+    }
 }
 
 // A freshly constructed network in blob order (the reference saves one when the named file is missing,
@@ -114,14 +158,17 @@ inline std::string load_network(WeightFile& w, const std::string& current, bool&
     if (read_azw(export_path + ".azw", w) || read_azw(export_path, w)) {
         std::cout << "Network loaded.\nPath: " << export_path << std::endl;
     } else if (std::ifstream(export_path).good()) {
-        // the trainer published a libtorch archive (util.h:108-139) and its flat-blob twin <path>.azw
-        // (tools/pt2blob.py, one-shot or --watch) is not there yet: keep playing with the weights in
-        // use and look again at the next load(), as a generator between two checkpoints would
-        if (current.empty())
-            throw Error("checkpoint " + export_path + " is a libtorch archive and " + export_path +
-                        ".azw does not exist: convert it with tools/pt2blob.py (or run it with --watch)");
-        std::cout << "Checkpoint " << export_path << " has no .azw twin yet. Resuming with network " << current << std::endl;
-        return current;
+        // the trainer's own file: a libtorch archive (util.h:108-139), read as it is
+        try {
+            read_pt(export_path, w);
+            std::cout << "Network loaded.\nPath: " << export_path << std::endl;
+        } catch (const pt::Error& e) {
+            // not (yet) a readable archive: a generator with weights keeps playing with them and looks again at its
+            // next load(); one without has nothing to play with
+            if (current.empty()) throw Error("checkpoint " + export_path + " cannot be read: " + e.what());
+            std::cout << "Checkpoint " << export_path << " cannot be read (" << e.what() << "). Resuming with network " << current << std::endl;
+            return current;
+        }
     } else {
         std::cout << "Model path provided by 'ckpt_location.txt' doesn't exist. Creating a new one." << std::endl;
         fresh(w);
