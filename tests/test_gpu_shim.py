@@ -43,15 +43,15 @@ def test_mcts_pvnetwork_shims_play_a_game(nthreads):
 def test_checkpoint_swap_mid_run_goes_through_the_group_load_and_the_device_fold(contexts):
     """host/swap_check: ckpt_location.txt rewritten under flock while self-play runs; load() hands the new
     blob to az_group_load_weights (one host -> device copy, an ncclBroadcast when the group spans more than one
-    GPU, BN fold + pack on the GPU) and the network that answers changes; an archive without its .azw twin keeps
-    the current weights."""
+    GPU, BN fold + pack on the GPU) and the network that answers changes; a checkpoint that cannot be read (cut
+    short) keeps the current weights."""
     exe = os.path.join(HOST, "swap_check")
     assert os.path.exists(exe), "build alphazero_amd/host first (__graft_entry__.build())"
     with tempfile.TemporaryDirectory() as d:
         out = subprocess.run([exe, str(contexts)], cwd=d, capture_output=True, text=True, timeout=180)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "swap ok: contexts %d" % contexts in out.stdout
-        assert "has no .azw twin yet" in out.stdout
+        assert "cannot be read" in out.stdout and "Resuming with network model_1.pt" in out.stdout
 
 
 @pytest.mark.skipif(find_libzmq() is None, reason="no libzmq for the PULL side")
