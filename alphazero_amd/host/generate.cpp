@@ -3,7 +3,7 @@
 // (generate.cpp:37-123): same argv, same ckpt_location.txt weight hand-off,
 // same PUSH stream on tcp://*:5555 in the trainer's 3-frame format, "press
 // enter" to stop (generate.cpp:19-23).  Instead of one game searched by
-// nthreads CPU threads it advances AZ_GAMES (default 512) games per GPU in lockstep
+// nthreads CPU threads it advances AZ_GAMES (default 512) games per GPU side by side
 // on every GPU named by AZ_GPUS ("all", a count, or a list; default: AZ_DEVICE or 0),
 // one host thread per GPU; new weights reach the GPUs by one RCCL broadcast; all rows
 // leave through the one PUSH socket.  <nthreads> is accepted and ignored.
@@ -42,6 +42,26 @@ int main(int argc, char const* argv[]) {
     std::cout << "GPUs: " << devices.size() << " | games per GPU: " << games << std::endl;
     az::ReplayBuffer<Env> buffer(GEN, "*", port ? port : "5555");
     agent.load();
+    // Every move's rounds as ONE launch of the persistent tower / tree pair, with simulations that end in a stored
+    // terminal leaf (no network call, mcts.hpp:232-233) riding along in a round: the producer's default wherever the
+    // contexts can run it (the one-launch tower, a GPU to themselves).  A short trial says whether they can; if
+    // not, or with AZ_PAIR=0, the rounds are lockstep launches.
+    bool pair = false;
+    if (!getenv("AZ_PAIR")) {
+        setenv("AZ_PAIR", "1", 1);
+        setenv("AZ_CHAIN", "6", 0);
+        try {
+            agent.begin();
+            agent.run(8);
+            (void)agent.stats();
+            pair = true;
+        } catch (const az::Error& e) {
+            setenv("AZ_PAIR", "0", 1);
+            std::cout << "The persistent tower / tree pair does not run here (" << e.what() << "); using lockstep rounds." << std::endl;
+        }
+    } else {
+        pair = atoi(getenv("AZ_PAIR")) != 0;
+    }
     agent.begin();
     const auto t0 = std::chrono::steady_clock::now();
     long long rows = 0;
@@ -78,7 +98,8 @@ int main(int argc, char const* argv[]) {
         std::cout << "{\"generate\": {\"seconds\": " << el << ", \"sims_per_s\": " << (double)s.sims_backed_up / el
                   << ", \"moves_per_s\": " << (double)s.moves / el << ", \"games\": " << s.games
                   << ", \"rows_per_s\": " << (double)rows / el << ", \"messages_per_s\": " << (double)rows * 8 / el
-                  << ", \"overlap\": " << (overlap ? "true" : "false") << ", \"gpus\": " << devices.size()
+                  << ", \"overlap\": " << (overlap ? "true" : "false") << ", \"persistent_pair\": " << (pair ? "true" : "false")
+                  << ", \"gpus\": " << devices.size()
                   << ", \"games_per_gpu\": " << games << ", \"replay_dropped\": " << s.replay_dropped << "}}" << std::endl;
     }
     alive = false;

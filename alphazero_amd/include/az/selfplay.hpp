@@ -49,9 +49,10 @@ template <class Env>
 class SelfPlay {
 public:
     // `games` slots PER GPU on each GPU of `devices`, as `contexts` engine contexts per GPU (default 1, or
-    // AZ_CONTEXTS; with 2 a tree block of one context runs on a CU beside a resident tower workgroup of the
-    // other: +0.7 % .. +6 % depending on the device, so it is opt-in).  One host thread per GPU issues the
-    // launches; RCCL carries the weights from the first GPU to the others (az_group_load_weights).
+    // AZ_CONTEXTS).  One host thread per GPU issues the launches; RCCL carries the weights from the first GPU to
+    // the others (az_group_load_weights).  With AZ_PAIR=1 in the environment run() is one launch of the persistent
+    // tower / tree pair per call on every context that can (az_selfplay_run_pair), AZ_CHAIN=k lets simulations
+    // that end in a stored terminal leaf ride along (az_selfplay_chain).
     SelfPlay(int games, int iter_budget, float vl = 3, float c_puct = 3, int device = 0, uint64_t seed = 0,
              int slot_base = 0, int contexts = 0, std::vector<int> devices = {})
         : G(games), budget(iter_budget) {
