@@ -35,7 +35,7 @@ EXPORTS = [
     "az_blokus_search_tower", "az_tower_shape",
     "az_blokus_noise_device", "az_blokus_selfplay_config", "az_blokus_selfplay_moves", "az_blokus_replay_drain", "az_blokus_selfplay_stats",
     "az_search", "az_search_begin", "az_search_select", "az_search_apply", "az_search_result",
-    "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_selfplay_run_pair", "az_pair_read", "az_selfplay_chain", "az_replay_drain",
+    "az_tree_clear", "az_tree_dump", "az_selfplay_begin", "az_selfplay_run", "az_selfplay_run_pair", "az_pair_read", "az_selfplay_chain", "az_tree_timing", "az_tree_timing_read", "az_replay_drain",
     "az_get_stats", "az_replay_symmetries", "az_profile_enable", "az_profile_read", "az_profile_overhead", "az_tower_is_fused", "az_host_env_step", "az_selfplay_batch",
 ]
 
@@ -349,6 +349,15 @@ class Engine:
     def selfplay_chain(self, max_chained):
         """simulations that end in a stored terminal leaf (no evaluation) a round may run back to back"""
         _chk(load().az_selfplay_chain(self.h, int(max_chained)))
+
+    def tree_timing(self, on):
+        _chk(load().az_tree_timing(self.h, int(bool(on))))
+
+    def tree_timing_read(self):
+        v = [C.c_double() for _ in range(5)]
+        n = C.c_int64()
+        _chk(load().az_tree_timing_read(self.h, *[C.byref(x) for x in v], C.byref(n)))
+        return dict(zip(("select_us", "step_us", "append_us", "backup_us", "root_us"), [x.value for x in v]), steps=n.value)
 
     def pair_read(self):
         us, n, r, ts = C.c_double(), C.c_int64(), C.c_int64(), C.c_double()

@@ -104,6 +104,7 @@ struct az_ctx {
     unsigned pair_base = 0;
     int n_cu = 0;
     int64_t pair_launches = 0, pair_rounds = 0;
+    unsigned long long tree_ticks[6] = {0, 0, 0, 0, 0, 0};   // phase clocks summed over the games at the last az_get_stats
     std::vector<std::pair<size_t, int>> pair_spans;       // (first event index, rounds) of the sampled pair launches
     // HIP-event sampling of the conv / tree kernels on the context's stream
     int prof_every = 0;
@@ -1155,6 +1156,7 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     unsigned long long k[32], sat = 0;
     memset(k, 0, sizeof k);
     if (!c->tower_only) {
+        HIPCHK(hipMemsetAsync(c->d_stats + 26, 0, 6 * sizeof(unsigned long long), c->stream));   // the phase clocks are added into
         az_launch_stats(c->stream, &c->d, c->d_stats);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(k, c->d_stats, sizeof k, hipMemcpyDeviceToHost, c->stream));
@@ -1175,6 +1177,23 @@ extern "C" int az_get_stats(az_ctx* c, az_stats* s) {
     s->error_games = (int32_t)k[23];
     s->max_nodes = (int32_t)k[24];
     s->max_edges = (int32_t)k[25];
+    for (int i = 0; i < 6; ++i) c->tree_ticks[i] = k[26 + i];
+    return AZ_OK;
+}
+
+extern "C" int az_tree_timing(az_ctx* c, int on) {
+    NEED(c); NEED_GAMES(c);
+    c->d.timing = on ? 1 : 0;
+    return AZ_OK;
+}
+
+extern "C" int az_tree_timing_read(az_ctx* c, double* select_us, double* step_us, double* append_us, double* backup_us,
+                                   double* root_us, int64_t* steps) {
+    NEED(c); NEED_GAMES(c); NEED(select_us); NEED(step_us); NEED(append_us); NEED(backup_us); NEED(root_us); NEED(steps);
+    az_stats st;
+    AZCHK(az_get_stats(c, &st));
+    *select_us = c->tree_ticks[0] * 0.01; *step_us = c->tree_ticks[1] * 0.01; *append_us = c->tree_ticks[2] * 0.01;
+    *backup_us = c->tree_ticks[3] * 0.01; *root_us = c->tree_ticks[4] * 0.01; *steps = (int64_t)c->tree_ticks[5];
     return AZ_OK;
 }
 

@@ -25,7 +25,10 @@ enum { AZ_ST_IDLE = 0, AZ_ST_RUN = 1 };
 enum { AZ_MODE_SEARCH = 0, AZ_MODE_SELFPLAY = 1 };
 
 // All per-game state, structure-of-arrays over the G games of one GPU.
-enum { AZ_GC_EVALS = 0, AZ_GC_DESCENTS = 1, AZ_GC_LEVELS = 2, AZ_GC_SCANNED = 3, AZ_GC_EXPANDED = 4, AZ_GC_RESTARTS = 5, AZ_GC_STRIDE = 8 };
+enum { AZ_GC_EVALS = 0, AZ_GC_DESCENTS = 1, AZ_GC_LEVELS = 2, AZ_GC_SCANNED = 3, AZ_GC_EXPANDED = 4, AZ_GC_RESTARTS = 5,
+       // phase clocks (100 MHz ticks, only while AzTreeDev::timing is set): the buckets of the reference's verbosity-3 report
+       AZ_GC_T_SELECT = 8, AZ_GC_T_STEP = 9, AZ_GC_T_APPEND = 10, AZ_GC_T_BACKUP = 11, AZ_GC_T_ROOT = 12, AZ_GC_N_STEP = 13,
+       AZ_GC_STRIDE = 16 };
 
 struct AzTreeDev {
     int G, N, A, K;
@@ -39,6 +42,7 @@ struct AzTreeDev {
     int slot_base;
     int budget;                 // selfplay: iter_budget of every search
     int chain;                  // simulations ending in a stored terminal leaf (no evaluation) a round may run back to back
+    int timing;                 // 1: the tree kernels clock their phases into g_ctr (az_tree_timing)
 
     // real game (= root position)
     uint8_t*  cells;            // [G][A]
@@ -95,7 +99,7 @@ struct AzTreeDev {
     // counters touched at most once per move: [0] sims of completed searches [2] moves [3] games
     // [4] rows [5] dropped of ring 0, [6] [7] of ring 1.  Everything counted per round lives per game (no hot shared word):
     unsigned long long* counters;
-    unsigned long long* g_ctr;          // [G][AZ_GC_STRIDE] per-game tallies (one 64-byte line per game, no shared hot word):
+    unsigned long long* g_ctr;          // [G][AZ_GC_STRIDE] per-game tallies (one 128-byte line per game, no shared hot word):
                                         //   AZ_GC_EVALS boards submitted to the evaluator, AZ_GC_DESCENTS descents that stood,
                                         //   AZ_GC_LEVELS tree levels they walked, AZ_GC_SCANNED child edges they read,
                                         //   AZ_GC_EXPANDED child edges written by expansions, AZ_GC_RESTARTS searches

@@ -32,6 +32,10 @@ extern "C" int az_tree_timing_read(unsigned long long* out) {
 #define AZ_SMEM_FIXED (AZ_CELLS_MAX + 4 * AZ_PATH_MAX * 4)
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// phase clocks of the verbosity-3 report (mcts.hpp:187-201,248-303): read only while the context asks for them
+#define AZ_TICK(d_) ((d_).timing ? __builtin_amdgcn_s_memrealtime() : 0ull)
+#define AZ_TOCK(d_, g_, slot_, t0_) do { if ((d_).timing && threadIdx.x == 0) \
+        (d_).g_ctr[(size_t)(g_) * AZ_GC_STRIDE + (slot_)] += __builtin_amdgcn_s_memrealtime() - (t0_); } while (0)
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << threadIdx.x) - 1ull;
 }
@@ -222,6 +226,7 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     const int rt = uni(d.to_move[g]);
     const int hl = uni(d.hist_len[g]);
     TTS(8);
+    const unsigned long long tk_a = AZ_TICK(d);
 
     if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
         // the leaf position = root position + the moves along the path (one lane per ply:
@@ -282,6 +287,8 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
         __syncthreads();
     }
     TTS(9);
+    if (pend != AZ_PEND_TERMINAL) AZ_TOCK(d, g, AZ_GC_T_APPEND, tk_a);   // _append_children (mcts.hpp:300-303)
+    const unsigned long long tk_b = AZ_TICK(d);
     if (pend == AZ_PEND_ROOT) {                                         // mcts.hpp:412-413
         if (threadIdx.x == 0) {
             d.root_n[g] = 1;
@@ -306,6 +313,7 @@ __device__ void az_apply(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     }
     if (threadIdx.x == 0) d.pending[slot] = AZ_PEND_NONE;
     __syncthreads();
+    AZ_TOCK(d, g, pend == AZ_PEND_ROOT ? AZ_GC_T_ROOT : AZ_GC_T_BACKUP, tk_b);
 }
 
 // ------------------------------------------------------------- select phase
@@ -343,6 +351,8 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     int scanned = 0;                                                    // child edges read by this descent
     float t0 = 0.f, t1 = 0.f;
     TTS(10);
+    const unsigned long long tk_s = AZ_TICK(d);
+    unsigned long long tk_e = 0ull;
     for (;; --ne) {
         const double s = sqrt((double)(par_n - 1));                     // node.hpp:54 sqrt(int) -> double
         float best_val = -100.f;                                        // mcts.hpp:355
@@ -429,6 +439,8 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
 #ifdef AZ_TREE_TIMING
         if (threadIdx.x == 0 && blockIdx.x == 7) az_tree_ts[22] = depth;
 #endif
+        AZ_TOCK(d, g, AZ_GC_T_SELECT, tk_s);                            // the descent (mcts.hpp:211-237)
+        tk_e = AZ_TICK(d);
         if (child <= -2) {                                              // stored terminal reward, mcts.hpp:232-233
             pend = AZ_PEND_TERMINAL;
             t0 = child == -2 ? 1.f : (child == -3 ? -1.f : 0.f);
@@ -462,6 +474,8 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     __syncthreads();
     for (int t = threadIdx.x; t < depth; t += AZ_WAVE) s_cells[s_act[t]] = 0;
     __syncthreads();
+    AZ_TOCK(d, g, AZ_GC_T_STEP, tk_e);                                  // Env::step + the board for the evaluator (mcts.hpp:248-271)
+    if (d.timing && threadIdx.x == 0) d.g_ctr[(size_t)g * AZ_GC_STRIDE + AZ_GC_N_STEP] += 1ull;
     return 0;
 }
 
@@ -727,7 +741,9 @@ az_round_pair_kernel(AzTreeDev, AzPairDev pr, int mode) {
 extern "C" __global__ void __launch_bounds__(AZ_WAVE)
 az_begin_kernel(AzTreeDev d, int budget) {
     const int g = blockIdx.x;
+    const unsigned long long tk_r = AZ_TICK(d);
     const int ok = az_make_root(d, g);
+    AZ_TOCK(d, g, AZ_GC_T_ROOT, tk_r);                                  // find + prune (mcts.hpp:385-421)
     if (threadIdx.x == 0) {
         d.sims_done[g] = 0;
         // the loop body runs once even for budget <= 0 (mcts.hpp:161-174)
@@ -867,11 +883,13 @@ extern "C" __global__ void __launch_bounds__(256) az_stats_kernel(AzTreeDev d, u
     __shared__ unsigned long long s_sum[8][4];
     __shared__ int s_max[2][4];
     unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tks[6] = {0, 0, 0, 0, 0, 0};                      // phase clocks, see az_tree_timing
     int mx[2] = {0, 0};
     for (int g = threadIdx.x; g < d.G; g += 256) {
         const unsigned long long* q = d.g_ctr + (size_t)g * AZ_GC_STRIDE;
         sum[0] += q[AZ_GC_EVALS]; sum[1] += q[AZ_GC_DESCENTS]; sum[2] += q[AZ_GC_LEVELS];
         sum[3] += q[AZ_GC_SCANNED]; sum[4] += q[AZ_GC_EXPANDED]; sum[5] += q[AZ_GC_RESTARTS];
+        for (int k = 0; k < 6; ++k) tks[k] += q[AZ_GC_T_SELECT + k];
         if (d.status[g] == AZ_ST_RUN) sum[6] += (unsigned long long)d.sims_done[g];
         sum[7] += d.err[g] != 0;
         mx[0] = max(mx[0], max(d.g_hw_nodes[g], d.n_nodes[g]));
@@ -885,6 +903,10 @@ extern "C" __global__ void __launch_bounds__(256) az_stats_kernel(AzTreeDev d, u
     for (int k = 0; k < 2; ++k) {
         for (int o = 32; o > 0; o >>= 1) mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64));
         if (lane == 0) s_max[k][wv] = mx[k];
+    }
+    for (int k = 0; k < 6; ++k) {                                        // rare path: plain atomics into the output words
+        for (int o = 32; o > 0; o >>= 1) tks[k] += __shfl_xor(tks[k], o, 64);
+        if (lane == 0 && tks[k]) atomicAdd(&out[26 + k], tks[k]);
     }
     __syncthreads();
     if (threadIdx.x < 16) out[threadIdx.x] = d.counters[threadIdx.x];

@@ -22,7 +22,8 @@ int main(int argc, char** argv) {
     bool done = false;
     int moves = 0;
     while (!done) {
-        az::FloatTensor policy = agent.search_probs(state, budget, 1);
+        // the second move is searched at verbosity 3: the reference's phase report (mcts.hpp:545-575)
+        az::FloatTensor policy = agent.search_probs(state, budget, moves == 1 ? 3 : 1);
         double sum = 0;
         for (float p : policy.v) sum += p;
         const int point = (int)az::argmax(policy);

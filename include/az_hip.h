@@ -398,6 +398,16 @@ int az_profile_enable(az_ctx*, int every);
 int az_tower_is_fused(const az_ctx*);
 /* Boards per evaluator launch during az_selfplay_run: G * leaves_per_round. */
 int az_selfplay_batch(const az_ctx*);
+/* The reference's verbosity-3 report (mcts.hpp:187-201,248-303,545-575) times its phases with std::chrono around
+ * the calls; here the tree kernels read the GPU's 100 MHz clock at the same boundaries while az_tree_timing is on and
+ * add the spans per game: select = the descent of __select_and_eval, step = Env::step at the leaf + handing the
+ * board to the evaluator, append = _append_children, backup = __backup, root = __make_root (find + prune, and the
+ * first expansion of a fresh root).  az_tree_timing_read returns the sums over all games since the counters were
+ * last cleared (az_selfplay_begin; az_ctx_create), in microseconds, and the number of leaf steps.  The network's own
+ * bucket is the evaluator launches' duration (az_profile_enable / az_profile_read). */
+int az_tree_timing(az_ctx*, int on);
+int az_tree_timing_read(az_ctx*, double* select_us, double* step_us, double* append_us, double* backup_us,
+                        double* root_us, int64_t* steps);
 int az_profile_read(az_ctx*, double* conv_avg_us, int64_t* conv_launches,
                     double* tree_avg_us, int64_t* tree_launches);
 /* What a span over-states its kernel by: the mean duration of the empty spans (two event records with nothing

@@ -33,6 +33,17 @@ def test_mcts_pvnetwork_shims_play_a_game(nthreads):
         for ln in lines:
             assert 0.9 < float(ln[5]) < 1.0
         assert os.path.exists(os.path.join(d, "shim_0.pt.azw"))     # created like util.h:94-97
+        # the verbosity-3 report of the second move's search (mcts.hpp:545-575): every bucket is there and has time in
+        # it, the counts are the search's (50 simulations, one evaluator call per round of the search)
+        rep = {}
+        for ln in out.stdout.splitlines():
+            for key in ("(Root Prune)", "(Select)", "(Eval)", "(Step)", "(Net)", "(Append)", "(Backup)"):
+                if ln.strip().startswith(key):
+                    rep[key] = float(ln.split("Total:")[1].split("|")[0])
+        assert set(rep) == {"(Root Prune)", "(Select)", "(Eval)", "(Step)", "(Net)", "(Append)", "(Backup)"}, out.stdout
+        assert rep["(Select)"] > 0 and rep["(Step)"] > 0 and rep["(Net)"] > 0 and rep["(Append)"] > 0 and rep["(Backup)"] > 0
+        assert abs(rep["(Eval)"] - (rep["(Step)"] + rep["(Net)"] + rep["(Append)"])) < 1e-3 * max(rep["(Eval)"], 1.0)
+        assert "Simulation count: 50" in out.stdout and "Net count:" in out.stdout
         bl = [ln for ln in out.stdout.splitlines() if ln.startswith("blokus game")][0].split()
         assert 40 <= int(bl[2]) <= 84 and int(bl[-1]) == 5 * 400                # the Blokus Env shim played a whole game
         pv = [ln for ln in out.stdout.splitlines() if ln.startswith("pvnet")][0].split()
