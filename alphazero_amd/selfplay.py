@@ -68,9 +68,9 @@ def run_selfplay(N, K, games_per_gpu, budget, Cs, blob_on_rank0, rounds, local_r
     elsewhere).  sink(cells, to_move, policy, reward) is called on rank 0 with
     the gathered rows.  Needs an MI355X per rank.
 
-    A rank's games run as `contexts` engine contexts on their own HIP streams: a tree
-    block fits on a CU beside a resident tower workgroup, so one context's tree round
-    executes under the other's tower kernel."""
+    A rank's games run as `contexts` engine contexts on their own HIP streams.  With
+    AZ_PAIR=1 in the environment (one context, the one-launch tower) the rounds of a
+    move run as one launch of the persistent tower / tree pair (az_selfplay_run_pair)."""
     from . import capi
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, _ = shard_slots(rank, world, games_per_gpu)
@@ -87,9 +87,11 @@ def run_selfplay(N, K, games_per_gpu, budget, Cs, blob_on_rank0, rounds, local_r
     for e in engs:
         e.load_weights_dev(wt.data_ptr(), wt.numel())
         e.selfplay_begin(budget)
+    import os
+    slice_rounds = max(1, budget) if os.environ.get("AZ_PAIR", "0") not in ("", "0") else 16
     done = 0
-    while done < rounds:                                   # slices keep every stream fed
-        k = min(16, rounds - done)
+    while done < rounds:                                   # slices keep every stream fed (a pair launch: a move's rounds)
+        k = min(slice_rounds, rounds - done)
         for e in engs:
             e.selfplay_run(k)
         done += k

@@ -86,26 +86,36 @@ def other_configs(device):
             r["algorithmic_hbm_frac"] = r["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
         return r
 
-    # configs[1]: gomoku 9x9, 256 games x 400 sims/move, self-play with the fused tower in 128-row tiles
+    # configs[1]: gomoku 9x9, 256 games x 400 sims/move, self-play with the fused tower in 128-row tiles, every move's
+    # rounds as one launch of the persistent pair with chained terminal simulations (as the headline).  With 256 games
+    # every CU holds ONE game, so a game's tree step cannot hide under another game's tile here: what the pair saves
+    # is the launch boundaries, what the chain saves is the evaluations of simulations that need none.
     N, G, budget, moves = 9, 256, 400, 30
     eng = capi.Engine(N, 5, G, Cs=Cs, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=0, device=device)
     eng.load_weights(synth.make_blob(N, 3, Cs, 0))
+    eng.selfplay_chain(6)
     eng.selfplay_begin(budget)
-    eng.selfplay_run(3 * budget)
-    eng.profile_enable(max(1, moves * budget * 2 // 3600))
+    for _ in range(3):
+        eng.selfplay_run_pair(budget)
+    eng.profile_enable(1)
     eng.sync()
     s0 = eng.stats()["sims_backed_up"]
     t0 = time.perf_counter()
-    eng.selfplay_run(moves * budget)
+    for _ in range(moves):
+        eng.selfplay_run_pair(budget)
     eng.sync()
     el = time.perf_counter() - t0
     st = eng.stats()
-    prof = eng.profile_read()
+    pr = eng.pair_read()
     A, C = N * N, Cs[0]
-    out.append({"config": 1, "workload": "gomoku 9x9 self-play, 256 concurrent games, 400 sims/move, NetConfig-2 tower, fp16 operands",
+    prof = {"conv_avg_us": pr["launch_avg_us"], "conv_launches": pr["launches"]}
+    out.append({"config": 1, "workload": "gomoku 9x9 self-play, 256 concurrent games, 400 evaluations per game per move as one launch of the "
+                                         "persistent pair (chain 6), NetConfig-2 tower, fp16 operands",
                 "value": (st["sims_backed_up"] - s0) / el, "unit": "sims/s", "seconds": el, "ms_per_round": el / (moves * budget) * 1e3,
-                "roofline": roof("az_tower_fused_kernel", (2.0 * 9 * A * C * C * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C) * G, prof),
-                "tree_round_avg_us": prof["tree_avg_us"], "error_games": st["error_games"]})
+                "sims_per_game_round": (st["sims_backed_up"] - s0) / (moves * budget * G),
+                "roofline": roof("az_tower_pair_kernel (%d rounds per launch, hand-over waits and the serial tree step included)" % budget,
+                                 (2.0 * 9 * A * C * C * 2 * (len(Cs) - 1) + 2.0 * 27 * A * C) * G * budget, prof),
+                "tree_step_avg_us": pr["tree_step_avg_us"], "error_games": st["error_games"]})
     eng.close()
 
     # configs[3]: Blokus 20x20 four players, 2048 games x 400 sims per search, the tower as evaluator
