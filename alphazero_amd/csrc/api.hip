@@ -27,6 +27,11 @@ static __device__ __align__(256) unsigned char scratch[AZ_STATIC_SCRATCH_BYTES];
 static unsigned char* g_scratch_ptr[AZ_MAX_DEVICES];
 static hipStream_t g_scratch_user[AZ_MAX_DEVICES];        // the stream of the last az_tower_forward_static call on the device
 static std::mutex g_scratch_mu;
+// Pair launches (az_selfplay_run_pair) of different contexts on one GPU must not overlap: each wants every CU for its
+// tower workgroups and the one tree-wave slot beside each, and two half-resident pairs would wait for each other
+// until their time-outs.  One event per GPU, recorded behind every pair launch; the next one waits for it.
+static hipEvent_t g_pair_done[AZ_MAX_DEVICES];
+static std::mutex g_pair_mu;
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -996,7 +1001,12 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     if (rounds < 1) return AZ_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
     if (!c->stream2) {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        // The tree kernel's stream is a high-priority one: the runtime keeps a pool of hardware queues per priority
+        // (four each), so this stream can never land on the hardware queue that carries the context's own stream --
+        // two kernels that wait for each other in one in-order queue would never both start.
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
         for (auto& e : c->pair_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     AzPairDev pr = c->pair;
@@ -1010,6 +1020,12 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     const char* dbg_s = getenv("AZ_PAIR_FLAGS");
     const int dbg = dbg_s ? atoi(dbg_s) : 0;
     pr.flags = (unsigned)(dbg & 3);
+    const int dev = c->cfg.device;
+    std::unique_lock<std::mutex> pair_lk(g_pair_mu);
+    if (dev < AZ_MAX_DEVICES) {
+        if (!g_pair_done[dev]) HIPCHK(hipEventCreateWithFlags(&g_pair_done[dev], hipEventDisableTiming));
+        else HIPCHK(hipStreamWaitEvent(c->stream, g_pair_done[dev], 0));      // behind any other context's pair on this GPU
+    }
     // the tree kernel starts behind everything queued on the context's stream, and the stream goes on behind both
     HIPCHK(hipEventRecord(c->pair_ev[0], c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, c->pair_ev[0], 0));
@@ -1026,6 +1042,8 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     if (!(dbg & 4)) az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
     HIPCHK(hipEventRecord(c->pair_ev[1], c->stream2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->pair_ev[1], 0));
+    if (dev < AZ_MAX_DEVICES) HIPCHK(hipEventRecord(g_pair_done[dev], c->stream));
+    pair_lk.unlock();
     HIPCHK(hipGetLastError());
     c->pair_base += (unsigned)rounds;
     c->rounds += rounds;

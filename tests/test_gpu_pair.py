@@ -165,3 +165,28 @@ def test_chain_needs_one_leaf_per_round():
         e.selfplay_chain(3)
     e.selfplay_chain(0)
     e.close()
+
+
+def test_pair_launches_of_two_contexts_on_one_gpu_take_turns():
+    """Two contexts that both queue pair launches without waiting for each other: each pair wants the whole chip, so
+    the library orders them on the GPU (an event per device); both finish and play what the lockstep rounds play."""
+    N, K, G, budget, rounds = 15, 5, 300, 24, 120
+    a, b, ref = _engine(N, K, G, budget, seed=1), _engine(N, K, G, budget, seed=2), _engine(N, K, G, budget, seed=2)
+    try:
+        for _ in range(3):
+            a.selfplay_run_pair(rounds // 3)
+            b.selfplay_run_pair(rounds // 3)
+        ref.selfplay_run(rounds)
+        a.sync()
+        b.sync()
+        ref.sync()
+        assert b.stats() == ref.stats()
+        assert a.stats()["sims_backed_up"] == ref.stats()["sims_backed_up"]
+        for g in (0, 7, G - 1):
+            db, dr = b.tree_dump(g), ref.tree_dump(g)
+            for k in db:
+                assert np.array_equal(db[k], dr[k])
+    finally:
+        a.close()
+        b.close()
+        ref.close()
