@@ -30,8 +30,9 @@ static std::mutex g_scratch_mu;
 // Pair launches (az_selfplay_run_pair) of different contexts on one GPU must not overlap: each wants every CU for its
 // tower workgroups and the one tree-wave slot beside each, and two half-resident pairs would wait for each other
 // until their time-outs.  One event per GPU, recorded behind every pair launch; the next one waits for it.
-static hipEvent_t g_pair_done[AZ_MAX_DEVICES];
-static std::mutex g_pair_mu;
+static hipEvent_t g_pair_done[AZ_MAX_DEVICES];          // per GPU: the end of the last pair launch of any context
+static const void* g_pair_last[AZ_MAX_DEVICES];         // ... and whose it was
+static std::mutex g_pair_mu[AZ_MAX_DEVICES];
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -104,7 +105,8 @@ struct az_ctx {
     // the persistent pair (az_selfplay_run_pair): the tree kernel's own stream, the events that order it against the
     // context's stream, the hand-over words, what the launches so far have published
     hipStream_t stream2 = nullptr;
-    hipEvent_t pair_ev[2] = {nullptr, nullptr};
+    hipEvent_t pair_join = nullptr;                     // the tree kernel of the last pair launch has ended
+    unsigned pair_ticket = 0;
     AzPairDev pair = {};
     unsigned pair_base = 0;
     int n_cu = 0;
@@ -260,9 +262,21 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         HIPCHK(hipMemcpy(d.noise, nz.data(), nz.size() * 4, hipMemcpyHostToDevice));
     }
     AZCHK(dalloc(c, &c->pair.plane_seq, S)); AZCHK(dalloc(c, &c->pair.eval_seq, S));
-    AZCHK(dalloc(c, &c->pair.abort, 4)); AZCHK(dalloc(c, &c->pair.busy, G));
+    AZCHK(dalloc(c, &c->pair.abort, 4)); AZCHK(dalloc(c, &c->pair.start, 4)); AZCHK(dalloc(c, &c->pair.busy, G));
     c->pair.plane_stride = (3 * A + 15) / 16 * 16;
     AZCHK(dalloc(c, &c->pair.planes_wt, S * (size_t)(c->pair.plane_stride / 4)));
+    {
+        // The pair's tree kernel gets a stream of its own, made here and not at the first pair launch: making a stream
+        // makes a hardware queue, for which the driver takes every queue of the process off the GPU and puts it back --
+        // running kernels are saved and restored, and a pair of another context that is saved in the middle of a launch
+        // need not come back with both kernels resident.  It is a high-priority stream: the runtime keeps a pool of
+        // hardware queues per priority (four each), so it can never land on the hardware queue that carries the
+        // context's own stream -- two kernels that wait for each other in one in-order queue would never both start.
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
+        HIPCHK(hipEventCreateWithFlags(&c->pair_join, hipEventDisableTiming));
+    }
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
@@ -335,6 +349,7 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     if (!c) return AZ_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->cfg.device >= 0 && c->cfg.device < AZ_MAX_DEVICES) {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         if (g_scratch_user[c->cfg.device] == c->stream) g_scratch_user[c->cfg.device] = nullptr;
@@ -342,8 +357,11 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->flip_ev) (void)hipEventDestroy(c->flip_ev);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    for (auto& e : c->pair_ev) if (e) (void)hipEventDestroy(e);
+    if (c->pair_join) (void)hipEventDestroy(c->pair_join);
+    if (c->cfg.device >= 0 && c->cfg.device < AZ_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_pair_mu[c->cfg.device]);
+        if (g_pair_last[c->cfg.device] == c) g_pair_last[c->cfg.device] = nullptr;
+    }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -977,11 +995,12 @@ static const char* pair_unfit(const az_ctx* c) {
 // A wait of the pair that ran out (the two kernels were not resident together): sticky, reported by every later call.
 static int pair_check(az_ctx* c) {
     if (!c->pair_launches) return AZ_OK;
-    unsigned ab = 0;
-    HIPCHK(hipMemcpy(&ab, c->pair.abort, 4, hipMemcpyDeviceToHost));
-    if (ab) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out: the two kernels were not "
-                                     "resident together (another process on this GPU, or a profiler that serialises launches); "
-                                     "the games of this context are no longer in step -- run such set-ups with az_selfplay_run");
+    unsigned ab[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(ab, c->pair.abort, 16, hipMemcpyDeviceToHost));
+    if (ab[0]) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out (the %s of game %u wanted word %u and saw %u): "
+                                        "the two kernels were not resident together (another process on this GPU, or a profiler that "
+                                        "serialises launches); the games of this context are no longer in step -- run such set-ups with "
+                                        "az_selfplay_run", (ab[1] >> 31) ? "tree wave" : "tower workgroup", ab[1] & 0x7FFFFFFFu, ab[2], ab[3]);
     return AZ_OK;
 }
 
@@ -1000,15 +1019,6 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     if (!c->have_weights) return fail(AZ_E_NOWEIGHTS, "az_load_weights has not been called");
     if (rounds < 1) return AZ_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (!c->stream2) {
-        // The tree kernel's stream is a high-priority one: the runtime keeps a pool of hardware queues per priority
-        // (four each), so this stream can never land on the hardware queue that carries the context's own stream --
-        // two kernels that wait for each other in one in-order queue would never both start.
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
-        for (auto& e : c->pair_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     AzPairDev pr = c->pair;
     pr.base = c->pair_base;
     pr.rounds = rounds;
@@ -1020,15 +1030,21 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     const char* dbg_s = getenv("AZ_PAIR_FLAGS");
     const int dbg = dbg_s ? atoi(dbg_s) : 0;
     pr.flags = (unsigned)(dbg & 3);
+    pr.ticket = ++c->pair_ticket;
     const int dev = c->cfg.device;
-    std::unique_lock<std::mutex> pair_lk(g_pair_mu);
+    std::unique_lock<std::mutex> pair_lk(g_pair_mu[dev < AZ_MAX_DEVICES ? dev : 0]);
+    // A pair wants every CU: a second pair on the GPU at the same time would leave neither resident.  The pair launches
+    // of the contexts of this process on one GPU take turns, and it is the host that waits for the other context's
+    // launch to finish: a wait on the GPU (hipStreamWaitEvent) leaves a blocked barrier packet at the head of this
+    // context's high-priority hardware queue for as long as the other pair runs, and the command processor then no
+    // longer serves a normal-priority queue that shares its pipe -- the other context's own stream, which never gets
+    // to signal the event.  For the same reason the tree kernel's stream waits for nothing of the context's stream
+    // here: the tree waves wait in the kernel for the tower kernel's start word instead.
     if (dev < AZ_MAX_DEVICES) {
         if (!g_pair_done[dev]) HIPCHK(hipEventCreateWithFlags(&g_pair_done[dev], hipEventDisableTiming));
-        else HIPCHK(hipStreamWaitEvent(c->stream, g_pair_done[dev], 0));      // behind any other context's pair on this GPU
+        else if (g_pair_last[dev] != c) HIPCHK(hipEventSynchronize(g_pair_done[dev]));
+        g_pair_last[dev] = c;
     }
-    // the tree kernel starts behind everything queued on the context's stream, and the stream goes on behind both
-    HIPCHK(hipEventRecord(c->pair_ev[0], c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->pair_ev[0], 0));
     const bool sampled = c->prof_every > 0 && c->prof_used + 2 <= c->prof_pool.size();
     if (sampled) { c->pair_spans.push_back({c->prof_used, rounds}); (void)hipEventRecord(c->prof_pool[c->prof_used], c->stream); }
     // round 1 of the launch evaluates what the last select left in leaf_planes: the tower reads planes_wt only
@@ -1040,8 +1056,9 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     if (blocks <= 0) return fail(AZ_E_STATE, "az_selfplay_run_pair: the persistent tower kernel does not fit");
     if (sampled) { (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream); c->prof_used += 2; }
     if (!(dbg & 4)) az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
-    HIPCHK(hipEventRecord(c->pair_ev[1], c->stream2));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->pair_ev[1], 0));
+    // the context's stream goes on behind both kernels (a normal-priority queue may wait for a high-priority one)
+    HIPCHK(hipEventRecord(c->pair_join, c->stream2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pair_join, 0));
     if (dev < AZ_MAX_DEVICES) HIPCHK(hipEventRecord(g_pair_done[dev], c->stream));
     pair_lk.unlock();
     HIPCHK(hipGetLastError());

@@ -115,6 +115,9 @@ struct AzTreeDev {
 //                                planes_wt with write-through stores, publishes plane_seq[g] = base + i + 1
 //   tower workgroup, tile t    : waits plane_seq[g] >= base + i for its boards (i = 1: ready before the launch),
 //                                evaluates, publishes eval_seq[g] = base + i
+// The tree kernel's stream does not wait for the tower kernel's stream: the tower kernel stores the launch's ticket
+// to start[0] when it begins (everything queued ahead of it on the context's stream has finished by then), and the
+// tree waves wait for that word before they touch a game.
 // A wait that lasts longer than timeout_ticks (the two kernels are not resident together) raises abort[0]; every
 // wave of both kernels then leaves at its next wait, so the grids always drain.
 struct AzPairDev {
@@ -122,7 +125,9 @@ struct AzPairDev {
     unsigned* eval_seq;             // [G]
     unsigned* planes_wt;            // [G][plane_stride / 4] the planes once more, as whole words stored write-through
     int       plane_stride;         // bytes per game in planes_wt: 3 A rounded up to 16
-    unsigned* abort;                // [4]
+    unsigned* abort;                // [4] [0] raised by a wait that ran out, [1..3] that wait's notes
+    unsigned* start;                // [4] [0] ticket of the last launch whose tower kernel has begun
+    unsigned  ticket;               // this launch's
     unsigned long long* busy;       // [G] 100 MHz ticks the tree wave worked on the game (waits excluded)
     unsigned  base;                 // evaluations of every game published by earlier launches
     int       rounds;
@@ -135,16 +140,24 @@ struct AzPairDev {
 __device__ __forceinline__ unsigned az_pair_peek(const unsigned* w) {
     return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // bypasses this CU's L1
 }
-// One lane's wait until *w has reached `want` (sequence numbers: compared as a signed difference).
+// One lane's wait until *w has reached `want` (sequence numbers: compared as a signed difference).  The lane whose
+// wait runs out notes who it is in abort[1..3] (tag, the value it wanted, the value it last saw) before it raises
+// abort[0]; with several such lanes the notes are of any one of them.
 template <int SLEEP>
-__device__ inline bool az_pair_wait(const unsigned* w, unsigned want, unsigned* abort, unsigned limit) {
+__device__ inline bool az_pair_wait(const unsigned* w, unsigned want, unsigned* abort, unsigned long long limit, unsigned tag) {
     if ((int)(az_pair_peek(w) - want) >= 0) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         __builtin_amdgcn_s_sleep(SLEEP);
-        if ((int)(az_pair_peek(w) - want) >= 0) return true;
+        const unsigned seen = az_pair_peek(w);
+        if ((int)(seen - want) >= 0) return true;
         if (az_pair_peek(abort) != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) {
+        // signed: a wave that was saved and restored elsewhere may read a counter a few ticks behind its first reading
+        if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > (long long)limit) {
+            __hip_atomic_store(abort + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort + 2, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }

@@ -1599,6 +1599,8 @@ az_tower_pair_kernel(AzTowerPairArgs) {
     KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const int rounds = ka->pr.rounds, tiles = ka->tiles;
     __builtin_amdgcn_s_setprio(3);                                       // ahead of the tree wave that shares this SIMD
+    if (blockIdx.x == 0 && threadIdx.x == 0)                             // the tree waves of this launch may go
+        __hip_atomic_store(ka->pr.start, ka->pr.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) s_go = 0;                                      // 0: wait for the tile's planes, 1: already acquired, -1: leave
     __syncthreads();
     bool warm = false;
@@ -1614,7 +1616,7 @@ az_tower_pair_kernel(AzTowerPairArgs) {
                     bool ok = true;
                     // round 1 evaluates the planes that were there before the launch
                     if ((int)threadIdx.x < ka->bpt && b < ka->B && i > 1 && !(ka->pr.flags & 1u))
-                        ok = az_pair_wait<4>(ka->pr.plane_seq + b, want, ka->pr.abort, ka->pr.timeout_ticks);
+                        ok = az_pair_wait<4>(ka->pr.plane_seq + b, want, ka->pr.abort, ka->pr.timeout_ticks, (unsigned)b);
                     const bool all_ok = __ballot(!ok) == 0ull;
                     // the planes were written by other CUs: drop this CU's L1 copies before any wave loads them
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -700,12 +700,19 @@ az_round_pair_kernel(AzTreeDev, AzPairDev pr, int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AzTreeArgs ka = (AzTreeArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const int G = ka->G;
+    {
+        // Nothing of this launch before the tower kernel of this launch has begun: it sits behind whatever else the
+        // context's stream holds (rounds launched one by one, a weight load), which may take long -- a bound of its
+        // own, 150 hand-over time-outs (ten minutes by default), so that the grid drains whatever happens.
+        const bool ok = az_pair_wait<100>(pr.start, pr.ticket, pr.abort, 150ull * pr.timeout_ticks, 0xC0000000u);
+        if (__ballot(!ok) != 0ull) return;
+    }
     for (int i = 1; i <= pr.rounds; ++i) {
         const unsigned want = pr.base + (unsigned)i;
         for (int g = blockIdx.x; g < G; g += gridDim.x) {
             const AzTreeDev& d = *AZ_TREE_ARGS(ka);
             // the tree is never the hurry (its planes are wanted a whole tile later): poll seldom, stay out of the tower's way
-            const bool ok = az_pair_wait<100>(pr.eval_seq + g, want, pr.abort, pr.timeout_ticks);
+            const bool ok = az_pair_wait<100>(pr.eval_seq + g, want, pr.abort, pr.timeout_ticks, 0x80000000u | (unsigned)g);
             if (__ballot(!ok) != 0ull) return;                          // a wait ran out somewhere: leave
             // the evaluation was stored write-through by another CU: drop this CU's L1 copies before reading it
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

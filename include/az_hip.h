@@ -241,6 +241,12 @@ int az_selfplay_chain(az_ctx*, int max_chained);
  * wait for each other in memory, so both must be resident at once.  If they are not (another process or context on
  * the GPU, a profiler that serialises launches), a wait runs out after AZ_PAIR_TIMEOUT_MS (default 4000), both
  * kernels leave, and az_sync / az_get_stats / az_pair_read return AZ_E_STATE from then on.
+ * The error text names the wait that ran out (tower workgroup or tree wave, game, the word it wanted and saw).
+ * The call returns once the launch is queued, like az_selfplay_run, with one exception: when the last pair launch on
+ * this GPU was another context's of this process, it first waits on the host for that launch to end (two pairs at
+ * once would leave neither resident; see api.hip for why the wait is not left to the GPU).  Work queued on the
+ * context's stream ahead of the launch must end within 150 time-outs (ten minutes by default): the tree waves are
+ * resident by then and give up after that.
  * With AZ_PAIR=1 in the environment az_selfplay_run takes this path whenever the context can. */
 int az_selfplay_run_pair(az_ctx*, int rounds);
 /* What the pair launches since az_profile_enable / az_selfplay_begin took: mean duration of the sampled tower

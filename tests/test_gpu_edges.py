@@ -304,7 +304,8 @@ def test_bench_with_eight_ranks_prints_one_line_that_adds_up():
     import sys
     from test_wire import free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AZ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    # (eight processes on one GPU: the persistent pair, which wants the GPU to itself, stays off whatever the environment says)
+    env = dict(os.environ, AZ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", AZ_PAIR="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
            "--games", "32", "--budget", "32", "--board", "9", "--full-games", "0", "--no-lockstep-probe"]

@@ -169,7 +169,7 @@ def test_chain_needs_one_leaf_per_round():
 
 def test_pair_launches_of_two_contexts_on_one_gpu_take_turns():
     """Two contexts that both queue pair launches without waiting for each other: each pair wants the whole chip, so
-    the library orders them on the GPU (an event per device); both finish and play what the lockstep rounds play."""
+    the library makes them take turns (the host waits for the other context's launch); both finish and play what the lockstep rounds play."""
     N, K, G, budget, rounds = 15, 5, 300, 24, 120
     a, b, ref = _engine(N, K, G, budget, seed=1), _engine(N, K, G, budget, seed=2), _engine(N, K, G, budget, seed=2)
     try:
@@ -190,3 +190,39 @@ def test_pair_launches_of_two_contexts_on_one_gpu_take_turns():
         a.close()
         b.close()
         ref.close()
+
+
+_FRESH = r"""
+import sys
+sys.path.insert(0, %r)
+from alphazero_amd import capi, synth
+N, K, G, budget = 15, 5, 300, 24
+def eng(seed):
+    e = capi.Engine(N, K, G, Cs=synth.NETCONFIG2, max_budget=budget, noise_mode=capi.AZ_NOISE_DEVICE, seed=seed)
+    e.load_weights(synth.make_blob(N, 3, synth.NETCONFIG2, 0))
+    e.selfplay_begin(budget)
+    return e
+es = [eng(s) for s in (11, 12, 13)]
+ref = eng(12)
+for _ in range(3):
+    for e in es:
+        e.selfplay_run_pair(20)
+        e.selfplay_run_pair(20)
+ref.selfplay_run(120)
+for e in es + [ref]:
+    e.sync()
+assert es[1].stats() == ref.stats()
+print("fresh ok", es[0].stats()["sims_backed_up"])
+"""
+
+
+def test_pair_launches_of_three_contexts_queued_from_a_fresh_process():
+    """The first thing a process does on the GPU: three contexts queue pair launches in turn without a host wait of
+    their own.  (The hardware queues the streams get depend on what the process made before; with the queues a fresh
+    process gets, a wait on the GPU for the other context's pair once left the command processor serving neither.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _FRESH % root], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fresh ok" in out.stdout
