@@ -30,7 +30,7 @@ EXPORTS = [
     "az_blokus_create", "az_blokus_destroy", "az_blokus_reset", "az_blokus_step", "az_blokus_legal_mask", "az_blokus_boards",
     "az_blokus_state", "az_blokus_playout", "az_blokus_sync", "az_blokus_stream", "az_blokus_orient", "az_blokus_host_state_size",
     "az_blokus_host_reset", "az_blokus_host_step", "az_blokus_host_legal", "az_blokus_host_info",
-    "az_blokus_search_config", "az_blokus_search_reuse", "az_blokus_tree_clear", "az_blokus_selfplay_row_cap", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
+    "az_blokus_search_config", "az_blokus_search_reuse", "az_blokus_search_leaves", "az_blokus_eval_slots", "az_blokus_tree_clear", "az_blokus_selfplay_row_cap", "az_blokus_set_noise", "az_blokus_search", "az_blokus_search_begin", "az_blokus_search_round",
     "az_blokus_eval_hash", "az_blokus_eval_io", "az_blokus_search_result", "az_blokus_search_stats",
     "az_blokus_search_tower", "az_tower_shape",
     "az_blokus_noise_device", "az_blokus_selfplay_config", "az_blokus_selfplay_moves", "az_blokus_replay_drain", "az_blokus_selfplay_stats",
@@ -479,11 +479,15 @@ class Blokus:
         _chk(load().az_blokus_playout(self.h, int(steps)))
 
     # -- MCTS ----------------------------------------------------------------
-    def search_config(self, vl=3.0, c_puct=3.0, max_budget=400, edge_cap=0, reuse=False):
+    def search_config(self, vl=3.0, c_puct=3.0, max_budget=400, edge_cap=0, reuse=False, leaves=1):
         """reuse: keep each game's tree between searches (__make_root + find, mcts.hpp:385-421); self-play then runs
-        the reference's loop in full (warm-up search per game, tree carried from move to move)"""
+        the reference's loop in full (warm-up search per game, tree carried from move to move).  leaves: descents per
+        game and round (MCTS(nthreads, ...), mcts.hpp:54-72): a round evaluates G * leaves positions"""
         if reuse:
             _chk(load().az_blokus_search_reuse(self.h, 1))
+        if leaves != 1:
+            _chk(load().az_blokus_search_leaves(self.h, int(leaves)))
+        self.leaves = int(leaves)
         _chk(load().az_blokus_search_config(self.h, vl, c_puct, int(max_budget), int(edge_cap)))
         self.K = int(max_budget)                    # policy entries kept per self-play row (selfplay_config refreshes it)
 

@@ -50,6 +50,7 @@ struct AzbDev {
     float vl; int c_puct_i;
     int edge_cap;           // arena slots per game
     int use_noise;
+    int L;                  // descents per game and round (az_blokus_search_leaves): evaluation slot g * L + k
     AzEdge*   edges;        // [G][edge_cap]  a node = one header slot {n = child count, child = player to move} + its child edges
     uint16_t* eact;         // [G][edge_cap]  action of each child edge
     // tree reuse across searches (__make_root + find, mcts.hpp:385-421), az_blokus_search_reuse:
@@ -68,17 +69,18 @@ struct AzbDev {
     int*      t_status;     // [G] 1 while the search runs
     int*      sims_done;    // [G]
     int*      sims_target;  // [G]
-    int*      pending;      // [G] AZ_PEND_*
-    int*      path_len;     // [G]
-    int*      path;         // [G][AZB_PATH_CAP] edge slots root -> leaf
-    uint8_t*  path_owner;   // [G][AZB_PATH_CAP] who chose at each level
-    float*    pend_result;  // [G][4] reward of a terminal leaf
-    uint32_t* leaf_bits;    // [G][91][20] legal set of the leaf awaiting its evaluation
-    int*      leaf_count;   // [G]
-    uint8_t*  leaf_player;  // [G]
-    uint8_t*  leaf_planes;  // [G][5][400] evaluator input
-    float*    policy;       // [G][91*400] evaluator output
-    float*    value;        // [G][4]
+    // per evaluation slot (S = G * L of them):
+    int*      pending;      // [S] AZ_PEND_*
+    int*      path_len;     // [S]
+    int*      path;         // [S][AZB_PATH_CAP] edge slots root -> leaf
+    uint8_t*  path_owner;   // [S][AZB_PATH_CAP] who chose at each level
+    float*    pend_result;  // [S][4] reward of a terminal leaf
+    uint32_t* leaf_bits;    // [S][91][20] legal set of the leaf awaiting its evaluation
+    int*      leaf_count;   // [S]
+    uint8_t*  leaf_player;  // [S]
+    uint8_t*  leaf_planes;  // [S][5][400] evaluator input
+    float*    policy;       // [S][91*400] evaluator output
+    float*    value;        // [S][4]
     float*    noise;        // [G][AZB_NOISE_CAP]
     int*      restarts;     // [G] searches restarted because the arena was full
     int*      search_restarts;  // [G] ... in the current search
@@ -407,8 +409,8 @@ __device__ void azb_planes_to(uint8_t* pl, const uint32_t* s_own, int to_move) {
         pl[4 * AZB_CELLS + i] = (uint8_t)to_move;
     }
 }
-__device__ void azb_write_planes(const AzbDev& d, int g, const uint32_t* s_own, int to_move) {
-    azb_planes_to(d.leaf_planes + (size_t)g * AZB_PLANES * AZB_CELLS, s_own, to_move);
+__device__ void azb_write_planes(const AzbDev& d, int slot, const uint32_t* s_own, int to_move) {
+    azb_planes_to(d.leaf_planes + (size_t)slot * AZB_PLANES * AZB_CELLS, s_own, to_move);
 }
 
 // dirichlet(n_actions, alpha = 0.05) of util.h:42-58 drawn on the device for the root being expanded
@@ -534,30 +536,35 @@ extern "C" __global__ void __launch_bounds__(64) azb_make_root_kernel(AzbDev d, 
         if (!keep) { d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; }
         d.root_moves[g] = mv;
         d.sims_done[g] = 0; d.sims_target[g] = budget > 1 ? budget : 1;
-        d.pending[g] = AZ_PEND_NONE; d.path_len[g] = 0; d.search_restarts[g] = 0;
+        for (int k = 0; k < d.L; ++k) { d.pending[g * d.L + k] = AZ_PEND_NONE; d.path_len[g * d.L + k] = 0; }
+        d.search_restarts[g] = 0;
         d.t_status[g] = AZ_ST_RUN;
     }
 }
 
-// Consume the evaluation of the previous round: expand (+ noise at the root) and back up.
-__device__ void azb_tree_apply(const AzbDev& d, int g) {
+// Consume evaluation slot k of the previous round: expand (+ noise at the root) and back up.
+__device__ void azb_tree_apply(const AzbDev& d, int g, int k) {
     const int lane = threadIdx.x;
-    const int pend = azb_uni(d.pending[g]);
+    const int slot = g * d.L + k;
+    const int pend = azb_uni(d.pending[slot]);
     if (pend == AZ_PEND_NONE) return;
     AzEdge* E = azb_E(d, g);
     uint16_t* EA = azb_EA(d, g);
-    const int plen = azb_uni(d.path_len[g]);
-    const int* path = d.path + (size_t)g * AZB_PATH_CAP;
+    const int plen = azb_uni(d.path_len[slot]);
+    const int* path = d.path + (size_t)slot * AZB_PATH_CAP;
     if (pend == AZ_PEND_ROOT || pend == AZ_PEND_LEAF) {
-        const int cnt = azb_uni(d.leaf_count[g]);
+        const int cnt = azb_uni(d.leaf_count[slot]);
         const int hdr = azb_uni(d.n_slots[g]);
         if (hdr + 1 + cnt > d.edge_cap) {
             // Arena full.  The first time in a search: drop the tree and search the position again from a fresh root
             // (mcts.hpp:392-414).  If it fills up again the position is too wide for the arena at this budget: take
             // the virtual loss of the unfinished descent back and end the search with the simulations it has.
+            // (The evaluations of this round that are still pending belong to the dropped tree and go with it; after a
+            // truncation they are applied as usual, each giving up the same way if it does not fit either.)
             if (azb_uni(d.search_restarts[g]) == 0 && pend != AZ_PEND_ROOT) {
                 if (lane == 0) {
-                    d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; d.sims_done[g] = 0; d.pending[g] = AZ_PEND_NONE;
+                    d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0; d.sims_done[g] = 0;
+                    for (int kk = 0; kk < d.L; ++kk) d.pending[g * d.L + kk] = AZ_PEND_NONE;
                     d.restarts[g] += 1; d.search_restarts[g] = 1;
                 }
             } else {
@@ -567,17 +574,20 @@ __device__ void azb_tree_apply(const AzbDev& d, int g) {
                     e->n = (int)((float)e->n - vl);
                     e->v = e->v + vl;
                 }
-                if (lane == 0) { d.sims_target[g] = d.sims_done[g]; d.pending[g] = AZ_PEND_NONE; d.truncated[g] += 1; }
+                if (lane == 0) {
+                    if (plen > 0) E[path[plen - 1]].child = -1;             // no longer waiting for an evaluation: a stub again
+                    d.sims_target[g] = d.sims_done[g]; d.pending[slot] = AZ_PEND_NONE; d.truncated[g] += 1;
+                }
             }
             __syncthreads();
             return;
         }
         const bool is_root = pend == AZ_PEND_ROOT;
         if (is_root && d.use_noise == 2) azb_device_noise(d, g, cnt);
-        const float* pol = d.policy + (size_t)g * AZB_ACTIONS;
+        const float* pol = d.policy + (size_t)slot * AZB_ACTIONS;
         const float* nz = d.noise + (size_t)g * AZB_NOISE_CAP;
-        const uint32_t* bits = d.leaf_bits + (size_t)g * AZB_SET_WORDS;
-        if (lane == 0) { AzEdge h = {0.f, cnt, 0.f, (int)d.leaf_player[g]}; E[hdr] = h; EA[hdr] = 0; }
+        const uint32_t* bits = d.leaf_bits + (size_t)slot * AZB_SET_WORDS;
+        if (lane == 0) { AzEdge h = {0.f, cnt, 0.f, (int)d.leaf_player[slot]}; E[hdr] = h; EA[hdr] = 0; }
         int base = hdr + 1;
         for (int c = 0; c < AZB_SET_WORDS; c += 64) {                  // words in (o, y) order = action order
             const int i = c + lane;
@@ -612,33 +622,42 @@ __device__ void azb_tree_apply(const AzbDev& d, int g) {
     if (pend == AZ_PEND_ROOT) {
         if (lane == 0) d.root_n[g] = 1;                                 // mcts.hpp:412-413
     } else {                                                            // __backup (mcts.hpp:328-345)
-        const float* res = pend == AZ_PEND_TERMINAL ? d.pend_result + 4 * g : d.value + 4 * g;
+        const float* res = pend == AZ_PEND_TERMINAL ? d.pend_result + 4 * slot : d.value + 4 * slot;
         const float vl = d.vl;
         for (int t = lane; t < plen; t += 64) {
             AzEdge* e = &E[path[t]];
-            const float value = res[d.path_owner[(size_t)g * AZB_PATH_CAP + t]];     // result[parent->player]
+            const float value = res[d.path_owner[(size_t)slot * AZB_PATH_CAP + t]];  // result[parent->player]
             e->n = (int)((float)e->n + (1.f - vl));
             e->v = e->v + (value + vl);
         }
         if (lane == 0) { d.root_n[g] = d.root_n[g] + 1; d.sims_done[g] = d.sims_done[g] + 1; }
     }
-    if (lane == 0) d.pending[g] = AZ_PEND_NONE;
+    if (lane == 0) d.pending[slot] = AZ_PEND_NONE;
     __syncthreads();
 }
 
-// One descent (__select_and_eval + _eval's env step, mcts.hpp:211-321).  s_* hold the root position on entry.
-__device__ void azb_tree_select(const AzbDev& d, int g, uint32_t* s_own, uint2* s_rows, const uint2* s_tab,
-                                uint32_t* s_bits, int* s_cnt, uint32_t* s_used, int* s_last, int* s_meta) {
+// A stub whose evaluation an earlier descent of this round is waiting for (between "not expanded", -1, and the terminal
+// codes, <= -16).  The reference's searcher thread would block on that node's lock (mcts.hpp:224) until the other
+// thread has expanded it; a descent that meets one here is taken back exactly and the round issues no more descents.
+#define AZB_CHILD_WAITING (-2)
+
+// One descent (__select_and_eval + _eval's env step, mcts.hpp:211-321) into evaluation slot k.  s_* hold the root
+// position on entry (and the leaf's on return).  Returns 1 when the round's descents must stop: a fresh root, or a
+// descent that met a waiting stub and was undone.
+__device__ int azb_tree_select(const AzbDev& d, int g, int k, uint32_t* s_own, uint2* s_rows, const uint2* s_tab,
+                               uint32_t* s_bits, int* s_cnt, uint32_t* s_used, int* s_last, int* s_meta,
+                               int* s_path, int* s_oldn, float* s_oldv) {
     const int lane = threadIdx.x;
+    const int slot = g * d.L + k;
     AzEdge* E = azb_E(d, g);
     const uint16_t* EA = azb_EA(d, g);
-    int* path = d.path + (size_t)g * AZB_PATH_CAP;
-    uint8_t* owners = d.path_owner + (size_t)g * AZB_PATH_CAP;
+    int* path = d.path + (size_t)slot * AZB_PATH_CAP;
+    uint8_t* owners = d.path_owner + (size_t)slot * AZB_PATH_CAP;
     if (azb_uni(d.n_nodes[g]) == 0) {                                   // fresh root: evaluate the root position
-        for (int i = lane; i < AZB_SET_WORDS; i += 64) d.leaf_bits[(size_t)g * AZB_SET_WORDS + i] = d.legal_bits[(size_t)g * AZB_SET_WORDS + i];
-        azb_write_planes(d, g, s_own, s_meta[0]);
-        if (lane == 0) { d.leaf_count[g] = s_meta[3]; d.leaf_player[g] = (uint8_t)s_meta[0]; d.pending[g] = AZ_PEND_ROOT; d.path_len[g] = 0; }
-        return;
+        for (int i = lane; i < AZB_SET_WORDS; i += 64) d.leaf_bits[(size_t)slot * AZB_SET_WORDS + i] = d.legal_bits[(size_t)g * AZB_SET_WORDS + i];
+        azb_write_planes(d, slot, s_own, s_meta[0]);
+        if (lane == 0) { d.leaf_count[slot] = s_meta[3]; d.leaf_player[slot] = (uint8_t)s_meta[0]; d.pending[slot] = AZ_PEND_ROOT; d.path_len[slot] = 0; }
+        return 1;
     }
     const float vl = d.vl;
     const float cpf = (float)d.c_puct_i;
@@ -665,6 +684,7 @@ __device__ void azb_tree_select(const AzbDev& d, int g, uint32_t* s_own, uint2* 
         const int ei = hdr + 1 + azb_uni(best_k);
         AzEdge e = E[ei];
         const int action = EA[ei];
+        if (lane == 0) { s_path[depth] = ei; s_oldn[depth] = e.n; s_oldv[depth] = e.v; }
         e.n = (int)((float)e.n + vl);                                   // mcts.hpp:225-227
         e.v = e.v - vl;
         if (lane == 0) { E[ei].n = e.n; E[ei].v = e.v; path[depth] = ei; owners[depth] = (uint8_t)owner; }
@@ -672,6 +692,12 @@ __device__ void azb_tree_select(const AzbDev& d, int g, uint32_t* s_own, uint2* 
         ++depth;
         const int child = azb_uni(e.child);
         if (child > 0) { hdr = child; par_n = azb_uni(e.n); continue; }
+        if (child == AZB_CHILD_WAITING) {                               // take the descent back: every edge of the path as it was
+            __syncthreads();
+            for (int t = lane; t < depth; t += 64) { E[s_path[t]].n = s_oldn[t]; E[s_path[t]].v = s_oldv[t]; }
+            __syncthreads();
+            return 1;
+        }
         if (child <= -16) {                                             // stored terminal reward (mcts.hpp:232-233)
             azb_unpack_reward(-16 - child, res);
             pend = AZ_PEND_TERMINAL;
@@ -685,34 +711,41 @@ __device__ void azb_tree_select(const AzbDev& d, int g, uint32_t* s_own, uint2* 
             if (lane == 0) E[ei].child = AZB_TERMINAL(azb_pack_reward(res));
             pend = AZ_PEND_TERMINAL;
         } else {
-            for (int i = lane; i < AZB_SET_WORDS; i += 64) d.leaf_bits[(size_t)g * AZB_SET_WORDS + i] = s_bits[i];
-            azb_write_planes(d, g, s_own, next);
-            if (lane == 0) { d.leaf_count[g] = cnt2; d.leaf_player[g] = (uint8_t)next; }
+            for (int i = lane; i < AZB_SET_WORDS; i += 64) d.leaf_bits[(size_t)slot * AZB_SET_WORDS + i] = s_bits[i];
+            azb_write_planes(d, slot, s_own, next);
+            if (lane == 0) { d.leaf_count[slot] = cnt2; d.leaf_player[slot] = (uint8_t)next; E[ei].child = AZB_CHILD_WAITING; }
             pend = AZ_PEND_LEAF;
         }
         break;
     }
     if (lane == 0) {
-        d.pending[g] = pend;
-        d.path_len[g] = depth;
-        if (pend == AZ_PEND_TERMINAL) for (int q = 0; q < 4; ++q) d.pend_result[4 * g + q] = res[q];
+        d.pending[slot] = pend;
+        d.path_len[slot] = depth;
+        if (pend == AZ_PEND_TERMINAL) for (int q = 0; q < 4; ++q) d.pend_result[4 * slot + q] = res[q];
     }
     __syncthreads();
+    return 0;
 }
 
-// One lockstep round: apply the pending evaluation, then (unless the search is complete) select the next leaf.
+// One lockstep round: apply the pending evaluations in slot order, then (unless the search is complete) up to L
+// descents, never more than the simulations still owed (mcts.hpp:161-174), each from the root position.
 extern "C" __global__ void __launch_bounds__(64) azb_round_kernel(AzbDev d) {
     AZB_SMEM_DECL;
+    __shared__ int s_path[AZB_PATH_CAP], s_oldn[AZB_PATH_CAP];
+    __shared__ float s_oldv[AZB_PATH_CAP];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (azb_uni(d.t_status[g]) != AZ_ST_RUN) return;
-    azb_tree_apply(d, g);
-    if (azb_uni(d.sims_done[g]) >= azb_uni(d.sims_target[g])) {
+    for (int k = 0; k < d.L; ++k) azb_tree_apply(d, g, k);
+    const int owed = azb_uni(d.sims_target[g]) - azb_uni(d.sims_done[g]);
+    if (owed <= 0) {
         if (lane == 0) d.t_status[g] = AZ_ST_IDLE;
         return;
     }
     azb_load_table(s_tab);
-    azb_load(d, g, s_own, s_used, s_last, s_meta);
-    azb_tree_select(d, g, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta);
+    for (int k = 0; k < d.L && k < owed; ++k) {
+        azb_load(d, g, s_own, s_used, s_last, s_meta);
+        if (azb_tree_select(d, g, k, s_own, s_rows, s_tab, s_bits, s_cnt, s_used, s_last, s_meta, s_path, s_oldn, s_oldv)) break;
+    }
 }
 
 extern "C" __global__ void azb_search_begin_kernel(AzbDev d, int budget) {
@@ -720,7 +753,8 @@ extern "C" __global__ void azb_search_begin_kernel(AzbDev d, int budget) {
     if (g >= d.G) return;
     d.n_slots[g] = 0; d.n_nodes[g] = 0; d.root_n[g] = 0;
     d.sims_done[g] = 0; d.sims_target[g] = budget > 1 ? budget : 1;     // the loop body runs once even for budget <= 0
-    d.pending[g] = AZ_PEND_NONE; d.path_len[g] = 0; d.search_restarts[g] = 0;
+    for (int k = 0; k < d.L; ++k) { d.pending[g * d.L + k] = AZ_PEND_NONE; d.path_len[g * d.L + k] = 0; }
+    d.search_restarts[g] = 0;
     d.t_status[g] = d.over[g] ? AZ_ST_IDLE : AZ_ST_RUN;
 }
 
@@ -946,7 +980,7 @@ extern "C" int az_blokus_create(az_blokus** out, int device, int G, uint64_t see
     az_blokus* b = new az_blokus;
     b->device = device;
     memset(&b->d, 0, sizeof b->d);
-    b->d.G = G; b->d.seed = seed; b->d.slot_base = game_slot_base;
+    b->d.G = G; b->d.seed = seed; b->d.slot_base = game_slot_base; b->d.L = 1;
     int rc = AZ_OK;
 #define BA(ptr, n) do { if (rc == AZ_OK) rc = balloc(b, &(ptr), (size_t)(n)); } while (0)
     BA(b->d.own, (size_t)G * 4 * AZB_N); BA(b->d.used, (size_t)G * 4); BA(b->d.last_piece, (size_t)G * 4);
@@ -1066,9 +1100,10 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
         BA(b->d.root_hist, (size_t)G * AZB_MAX_MOVES); BA(b->d.queue, (size_t)G * b->d.q_cap); BA(b->d.warm, G);
     }
     BA(b->d.n_slots, G); BA(b->d.n_nodes, G); BA(b->d.root_n, G); BA(b->d.t_status, G); BA(b->d.sims_done, G); BA(b->d.sims_target, G);
-    BA(b->d.pending, G); BA(b->d.path_len, G); BA(b->d.path, (size_t)G * AZB_PATH_CAP); BA(b->d.path_owner, (size_t)G * AZB_PATH_CAP);
-    BA(b->d.pend_result, (size_t)G * 4); BA(b->d.leaf_bits, (size_t)G * AZB_SET_WORDS); BA(b->d.leaf_count, G); BA(b->d.leaf_player, G);
-    BA(b->d.leaf_planes, (size_t)G * AZB_PLANES * AZB_CELLS); BA(b->d.policy, (size_t)G * AZB_ACTIONS); BA(b->d.value, (size_t)G * 4);
+    const size_t S = (size_t)G * b->d.L;                            // evaluation slots per round
+    BA(b->d.pending, S); BA(b->d.path_len, S); BA(b->d.path, S * AZB_PATH_CAP); BA(b->d.path_owner, S * AZB_PATH_CAP);
+    BA(b->d.pend_result, S * 4); BA(b->d.leaf_bits, S * AZB_SET_WORDS); BA(b->d.leaf_count, S); BA(b->d.leaf_player, S);
+    BA(b->d.leaf_planes, S * AZB_PLANES * AZB_CELLS); BA(b->d.policy, S * AZB_ACTIONS); BA(b->d.value, S * 4);
     BA(b->d.noise, (size_t)G * AZB_NOISE_CAP); BA(b->d.restarts, G); BA(b->d.noise_ctr, G);
     BA(b->d.search_restarts, G); BA(b->d.truncated, G);
 #undef BA
@@ -1077,6 +1112,19 @@ extern "C" int az_blokus_search_config(az_blokus* b, float vl, float c_puct, int
     BHIP(hipDeviceSynchronize());            // the zero fills ran on the null stream, the context's stream does not wait for it
     return AZ_OK;
 }
+
+// Before az_blokus_search_config: `leaves` descents per game and round, the counterpart of the reference's searcher
+// threads on one tree (MCTS(nthreads, ...), mcts.hpp:54-72; the m,n,k search's az_config.leaves_per_round).  A round
+// then evaluates G * leaves positions; a descent that reaches a leaf an earlier descent of the round is waiting on is
+// taken back and ends the round's descents for that game (mcts.hpp:224: the thread would block there).
+extern "C" int az_blokus_search_leaves(az_blokus* b, int leaves) {
+    BNEED(b);
+    if (b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_leaves must come before az_blokus_search_config (it sizes the evaluator's buffers)");
+    if (leaves < 1 || leaves > 16) return bfail(AZ_E_ARG, "leaves must be 1..16");
+    b->d.L = leaves;
+    return AZ_OK;
+}
+extern "C" int az_blokus_eval_slots(const az_blokus* b) { return b ? b->d.G * b->d.L : 0; }
 
 // Before az_blokus_search_config: keep each game's tree between searches, as the reference's MCTS object does
 // (__make_root + find, mcts.hpp:385-421).  Costs a second arena per game.
@@ -1170,7 +1218,7 @@ extern "C" int az_blokus_eval_hash(az_blokus* b) {
     BNEED(b);
     if (!b->d.edges) return bfail(AZ_E_STATE, "az_blokus_search_config has not been called");
     BHIP(hipSetDevice(b->device));
-    hipLaunchKernelGGL(azb_eval_hash_kernel, dim3(b->d.G), dim3(256), 0, b->stream, b->d.leaf_planes, b->d.policy, b->d.value);
+    hipLaunchKernelGGL(azb_eval_hash_kernel, dim3(b->d.G * b->d.L), dim3(256), 0, b->stream, b->d.leaf_planes, b->d.policy, b->d.value);
     BHIP(hipGetLastError());
     return AZ_OK;
 }
@@ -1180,9 +1228,10 @@ extern "C" int az_blokus_eval_hash(az_blokus* b) {
 extern "C" int az_blokus_search(az_blokus* b, int budget) {
     AZB_CHK(az_blokus_search_begin(b, budget));
     const int bb = budget > 1 ? budget : 1;
-    for (int r = 0; r < bb + 2; ++r) {
+    const int first = (bb + b->d.L - 1) / b->d.L + 2;                  // rounds before anybody is asked (L descents each at best)
+    for (int r = 0; r < first; ++r) {
         AZB_CHK(az_blokus_search_round(b, nullptr));
-        if (r < bb + 1) AZB_CHK(az_blokus_eval_hash(b));
+        if (r < first - 1) AZB_CHK(az_blokus_eval_hash(b));
     }
     for (int extra = 0;; ++extra) {                                  // restarts (a full arena) need more rounds
         int run = 0;
@@ -1201,7 +1250,8 @@ extern "C" int az_blokus_search_tower(az_blokus* b, az_ctx* tower, int budget) {
     AZB_CHK(az_tower_shape(tower, &N, &ci, &co, &vd, &mb));
     if (N != AZB_N || ci != AZB_PLANES || co != AZB_ORIENTS || vd != AZB_PLAYERS)
         return bfail(AZ_E_ARG, "the tower must be 20x20 with c_in 5, c_out 91, value_dim 4");
-    if (mb < b->d.G) return bfail(AZ_E_ARG, "the tower context takes batches of " + std::to_string(mb) + ", the search has " + std::to_string(b->d.G) + " games");
+    const int S = b->d.G * b->d.L;
+    if (mb < S) return bfail(AZ_E_ARG, "the tower context takes batches of " + std::to_string(mb) + ", a round of the search evaluates " + std::to_string(S) + " positions");
     // the tower's kernels read this handle's leaf planes and write its policy / value buffers in place
     if (az_ctx_device(tower) != b->device)
         return bfail(AZ_E_ARG, "the tower lives on GPU " + std::to_string(az_ctx_device(tower)) + ", the Blokus games on GPU " +
@@ -1212,17 +1262,18 @@ extern "C" int az_blokus_search_tower(az_blokus* b, az_ctx* tower, int budget) {
     const bool dense = getenv("AZ_BLOKUS_DENSE_POLICY") != nullptr;     // A/B: the full [91,20,20] policy per leaf
     AZB_CHK(az_blokus_search_begin(b, budget));
     const int bb = budget > 1 ? budget : 1;
+    const int first = (bb + b->d.L - 1) / b->d.L + 1;
     for (int r = 0, extra = 0;; ++r) {
         int run = 1;
-        AZB_CHK(az_blokus_search_round(b, r < bb + 1 ? nullptr : &run));          // past the expected end: ask who is still searching
+        AZB_CHK(az_blokus_search_round(b, r < first ? nullptr : &run));           // past the expected end: ask who is still searching
         if (!run) break;
-        if (r >= bb + 1 && ++extra > 4 * (bb + 2)) return bfail(AZ_E_STATE, "search did not finish within its round bound");
+        if (r >= first && ++extra > 4 * (bb + 2)) return bfail(AZ_E_STATE, "search did not finish within its round bound");
         // the tree kernel's leaves -> the tower (its own stream) -> back: two event hand-offs, no host wait
         BHIP(hipEventRecord(b->ev_tree, b->stream));
         BHIP(hipStreamWaitEvent(ts, b->ev_tree, 0));
         // (only the priors the expansion will read: the leaf's legal actions, about 300 of the 36 400 entries)
-        if (dense) AZB_CHK(az_tower_forward_dev(tower, b->d.leaf_planes, b->d.G, b->d.policy, b->d.value));
-        else AZB_CHK(az_tower_forward_masked_dev(tower, b->d.leaf_planes, b->d.G, b->d.policy, b->d.value, b->d.leaf_bits));
+        if (dense) AZB_CHK(az_tower_forward_dev(tower, b->d.leaf_planes, S, b->d.policy, b->d.value));
+        else AZB_CHK(az_tower_forward_masked_dev(tower, b->d.leaf_planes, S, b->d.policy, b->d.value, b->d.leaf_bits));
         BHIP(hipEventRecord(b->ev_eval, ts));
         BHIP(hipStreamWaitEvent(b->stream, b->ev_eval, 0));
     }

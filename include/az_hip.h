@@ -344,12 +344,21 @@ int az_blokus_search_config(az_blokus*, float vl, float c_puct, int max_budget, 
  * one of the n_moves steps of that game), the tree carried from move to move, cleared at the game's end
  * (generate.cpp:113); a row then holds up to az_blokus_selfplay_row_cap() = 4 * max_budget policy entries. */
 int az_blokus_search_reuse(az_blokus*, int on);
+/* Before az_blokus_search_config: `leaves` (1..16) descents per game and round, the counterpart of MCTS(nthreads, ...)'s
+ * searcher threads on one tree (mcts.hpp:54-72,161-174, virtual loss mcts.hpp:225-227) and of az_config.leaves_per_round
+ * for the m,n,k games: a round evaluates az_blokus_eval_slots() = G * leaves positions (the evaluator's buffers and the
+ * tower's batch are that large; slot g * leaves + k), applies them in slot order and issues up to `leaves` descents per
+ * game, never more than the simulations still owed.  A descent that reaches a leaf an earlier descent of the round
+ * is waiting on is taken back exactly and ends that game's descents for the round (the reference's thread would
+ * block on the node's lock, mcts.hpp:224). */
+int az_blokus_search_leaves(az_blokus*, int leaves);
+int az_blokus_eval_slots(const az_blokus*);
 int az_blokus_tree_clear(az_blokus*);
 int az_blokus_selfplay_row_cap(const az_blokus*);
 int az_blokus_set_noise(az_blokus*, const float* noise /* [G,n] or NULL = no noise */, int n);
 int az_blokus_search(az_blokus*, int budget);
 /* the same search with the leaves evaluated by `tower`, a context created with N = 20, c_in = 5, c_out = 91,
- * value_dim = 4 and G >= the number of Blokus games, on the same GPU (the Evaluator + PVNetwork pair of
+ * value_dim = 4 and G >= az_blokus_eval_slots(), on the same GPU (the Evaluator + PVNetwork pair of
  * evaluator.hpp:80-124 / network.hpp:117-123 for this Env): nothing leaves the device between the rounds */
 int az_blokus_search_tower(az_blokus*, az_ctx* tower, int budget);
 int az_blokus_search_begin(az_blokus*, int budget);

@@ -331,6 +331,21 @@ def blokus_search(game, budget, noise=None, vl=3.0, c_puct=3.0):
     return out
 
 
+def blokus_set_leaves(leaves):
+    """descents per round of every Blokus search of the oracle from here on (MCTS(nthreads, ...), mcts.hpp:54-72,
+    as lockstep rounds); 1 = one simulation after the other"""
+    lib().azo_blokus_set_leaves(int(leaves))
+
+
+def blokus_round_check(game, budget, vl=3.0, c_puct=3.0):
+    """the same fresh-root search through simulate() and through round_k(leaves = 1): both visit-count vectors"""
+    k = game.legal()[1]
+    a, b = np.zeros(k, np.int32), np.zeros(k, np.int32)
+    got = lib().azo_blokus_round_check(game.h, int(budget), C.c_float(vl), C.c_float(c_puct), _p(a, C.c_int32), _p(b, C.c_int32), k)
+    assert got == k
+    return a, b
+
+
 class BlokusMCTS:
     """The reference's MCTS object for one Blokus game of the oracle: the tree is kept between searches
     (__make_root + find, mcts.hpp:385-421), clear() drops it (mcts.hpp:462-465)."""

@@ -282,6 +282,7 @@ struct TNode {
     int action = -1;
     int player = 0;                 /* to move here (chooses among the children) */
     bool expanded = false, terminal = false;
+    bool waiting = false;           /* an earlier descent of the running round is waiting for this leaf's evaluation */
     float reward[NP] = {0, 0, 0, 0};
     std::vector<TNode*> kids;       /* in action-index order */
     ~TNode() { for (TNode* k : kids) delete k; }
@@ -368,11 +369,106 @@ void simulate(Search& s) {
     s.root_n++;
 }
 
+/* One round of a search with `leaves` searcher threads on one tree (MCTS(nthreads, ...), mcts.hpp:54-72,161-174), as the
+ * lockstep rounds run it: up to `leaves` descents one after the other, never more than `owed`, each leaving its virtual
+ * loss on its path (mcts.hpp:225-227); a descent that reaches a leaf an earlier descent of the round is waiting on is
+ * taken back exactly and ends the round's descents (the reference's thread would block on the node's lock,
+ * mcts.hpp:224).  Then the leaves are evaluated and every descent is finished in the order it was issued: expand,
+ * back up.  Returns the number of simulations the round completed.  leaves = 1 is simulate(). */
+int round_k(Search& s, int leaves, int owed) {
+    struct Slot {
+        std::vector<std::pair<TNode*, int>> path;
+        float result[NP] = {0, 0, 0, 0};
+        TNode* leaf = nullptr;          /* to expand at apply time */
+        Game g;
+    };
+    std::vector<Slot> slots;
+    for (int k = 0; k < leaves && k < owed; ++k) {
+        Slot sl;
+        TNode* node = s.root;
+        int par_n = s.root_n;
+        std::vector<int> actions;
+        std::vector<std::pair<int, float>> old;
+        bool undone = false;
+        for (;;) {
+            const double sq = std::sqrt((double)(par_n - 1));
+            float best = -100.f;
+            TNode* pick = nullptr;
+            for (TNode* c : node->kids) {
+                const float cp = (float)s.c_puct_i * c->p;
+                const float q = c->n != 0 ? c->v / (float)c->n : 0.f;
+                const float val = (float)((double)q + (double)cp * sq / (double)(1 + c->n));
+                if (val > best) { best = val; pick = c; }
+            }
+            sl.path.push_back({pick, node->player});
+            actions.push_back(pick->action);
+            old.push_back({pick->n, pick->v});
+            pick->n = (int)((float)pick->n + s.vl);
+            pick->v = pick->v - s.vl;
+            if (pick->waiting) {
+                for (size_t t = 0; t < sl.path.size(); ++t) { sl.path[t].first->n = old[t].first; sl.path[t].first->v = old[t].second; }
+                undone = true;
+                break;
+            }
+            if (pick->terminal) { for (int p = 0; p < NP; ++p) sl.result[p] = pick->reward[p]; break; }
+            if (!pick->expanded) {
+                Game g = s.root_state;
+                float rew[NP];
+                int done = 0;
+                for (int a : actions) done = step(g, a, rew);
+                if (done == 1) {
+                    pick->terminal = true;
+                    for (int p = 0; p < NP; ++p) { pick->reward[p] = rew[p]; sl.result[p] = rew[p]; }
+                } else { pick->waiting = true; sl.leaf = pick; sl.g = g; }
+                break;
+            }
+            node = pick;
+            par_n = pick->n;
+        }
+        if (undone) break;
+        slots.push_back(sl);
+    }
+    for (Slot& sl : slots) {
+        if (sl.leaf) { expand(s, sl.leaf, sl.g, nullptr, sl.result); sl.leaf->waiting = false; }
+        for (auto& pr : sl.path) {
+            TNode* c = pr.first;
+            c->n = (int)((float)c->n + (1.f - s.vl));
+            c->v = c->v + (sl.result[pr.second] + s.vl);
+        }
+        s.root_n++;
+    }
+    return (int)slots.size();
+}
+
 }  // namespace
 
 extern "C" {
 
 void azo_blokus_eval_hash(const uint8_t* planes, float* policy, float* value) { eval_hash(planes, policy, value); }
+
+/* descents per round of the searches below (1 = one simulation after the other, the default);
+ * azo_blokus_round_check: the same fresh-root search through simulate() and through round_k(.., 1, ..), the root
+ * children's visit counts of both (a self-check of round_k) */
+static int g_leaves = 1;
+void azo_blokus_set_leaves(int leaves) { g_leaves = leaves < 1 ? 1 : leaves; }
+int azo_blokus_round_check(void* h, int budget, float vl, float c_puct, int32_t* n_a, int32_t* n_b, int cap) {
+    Game& g = *(Game*)h;
+    int ka = 0, kb = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        Search s;
+        s.root_state = g; s.vl = vl; s.c_puct_i = (int)c_puct;
+        s.root = new TNode;
+        float value[NP];
+        expand(s, s.root, g, nullptr, value);
+        s.root_n = 1;
+        if (pass == 0) for (int i = 0; i < budget; ++i) simulate(s);
+        else for (int done = 0; done < budget;) done += round_k(s, 1, budget - done);
+        int k = 0;
+        for (TNode* c : s.root->kids) { if (k < cap) (pass == 0 ? n_a : n_b)[k] = c->n; ++k; }
+        (pass == 0 ? ka : kb) = k;
+    }
+    return ka == kb ? ka : -1;
+}
 
 /* search_probs from the game's current position: fresh root, `budget` simulations (at least one).
  * noise f32 [n_legal] or null.  Outputs for the root's children, in action order: actions, n, v, p (each sized
@@ -389,7 +485,8 @@ int azo_blokus_search(void* h, int budget, float vl, float c_puct, const float* 
     expand(s, s.root, g, noise, value);
     s.root_n = 1;                                                                          /* mcts.hpp:412-413 */
     const int b = budget > 1 ? budget : 1;
-    for (int i = 0; i < b; ++i) simulate(s);
+    if (g_leaves <= 1) for (int i = 0; i < b; ++i) simulate(s);
+    else for (int done = 0; done < b;) done += round_k(s, g_leaves, b - done);
     int k = 0;
     for (TNode* c : s.root->kids) { actions[k] = c->action; n[k] = c->n; v[k] = c->v; p[k] = c->p; ++k; }
     *root_n = s.root_n;
@@ -457,7 +554,8 @@ int azo_blokus_mcts_search(void* h, void* game, int budget, const float* noise,
     m->have = true;
     m->root_hist.assign(g.hist, g.hist + g.moves);
     const int b = budget > 1 ? budget : 1;
-    for (int i = 0; i < b; ++i) simulate(s);
+    if (g_leaves <= 1) for (int i = 0; i < b; ++i) simulate(s);
+    else for (int done = 0; done < b;) done += round_k(s, g_leaves, b - done);
     int k = 0;
     for (TNode* c : s.root->kids) { actions[k] = c->action; n[k] = c->n; v[k] = c->v; p[k] = c->p; ++k; }
     *root_n = s.root_n;

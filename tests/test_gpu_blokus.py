@@ -167,6 +167,107 @@ def test_search_matches_the_oracle_bit_for_bit():
         assert np.array_equal(again["n"], want["n"]) and np.array_equal(again["v"], want["v"])
 
 
+@pytest.mark.parametrize("leaves", [2, 5])
+def test_search_with_several_descents_per_round_matches_the_oracle(leaves):
+    """az_blokus_search_leaves: the reference's searcher threads on one tree (MCTS(nthreads, ...), mcts.hpp:54-72) as
+    `leaves` descents per game and round, virtual loss between them, a descent that runs into a leaf the round is
+    already waiting on taken back.  Root statistics of every game against the oracle's rounds, bit for bit: fresh
+    roots with noise at several depths of the game (skipped players, terminal leaves), then with tree reuse across a
+    move; the visit total is the budget whatever the number of rounds."""
+    G, budget, seed = 8, 41, 5                             # 41: the last round issues fewer descents than `leaves`
+    depth = [0, 1, 7, 20, 41, 52, 58, 60]
+    dev = capi.Blokus(G, seed=seed)
+    dev.search_config(vl=3.0, c_puct=3.0, max_budget=budget, reuse=True, leaves=leaves)
+    assert capi.load().az_blokus_eval_slots(dev.h) == G * leaves
+    ref = [azo.Blokus() for _ in range(G)]
+    for g in range(G):
+        for mv in range(depth[g]):
+            if ref[g].over:
+                break
+            a, _, _ = ref[g].random_move(seed, g, mv)
+            acts = np.full(G, -1, np.int32)
+            acts[g] = a
+            dev.step(acts)
+    _, count = dev.legal_mask(want_mask=False)
+    noise = np.zeros((G, int(count.max())), np.float32)
+    for g in range(G):
+        if count[g]:
+            noise[g, :count[g]] = azo.dirichlet(300 + g, int(count[g]))[0]
+    dev.set_noise(noise)
+    agents = [azo.BlokusMCTS() for _ in range(G)]
+    azo.blokus_set_leaves(leaves)
+    try:
+        def check(tag, with_noise):
+            live = 0
+            for g in range(G):
+                got = dev.search_result(g)
+                if ref[g].over:
+                    continue
+                live += 1
+                want = agents[g].search(ref[g], budget, noise[g, :count[g]] if with_noise else None)
+                assert got["root_n"] == want["root_n"], (tag, g, got["root_n"], want["root_n"])
+                for k in ("actions", "n", "v", "p"):
+                    assert np.array_equal(got[k], want[k]), (tag, g, k)
+            return live
+        dev.search(budget)
+        assert check("fresh", True) >= 6
+        for g in range(G):
+            if not ref[g].over:
+                assert dev.search_result(g)["n"].sum() == budget
+        # a move (the most visited child), then a search on the kept subtree
+        acts = np.full(G, -1, np.int32)
+        for g in range(G):
+            if ref[g].over:
+                continue
+            r = dev.search_result(g)
+            acts[g] = r["actions"][int(np.argmax(r["n"]))]
+            ref[g].step(int(acts[g]))
+        dev.step(acts)
+        dev.set_noise(None)                                # (a child that was never expanded gives a fresh root)
+        dev.search(budget)
+        check("after a move", False)
+        st = dev.search_stats()
+        assert st["restarts"] == 0
+        # fewer rounds than simulations: several descents per round did happen
+        assert st["rounds"] < 2 * (budget + 3)
+    finally:
+        azo.blokus_set_leaves(1)
+
+
+def test_oracle_rounds_of_one_descent_are_the_plain_simulations():
+    g = azo.Blokus()
+    for mv in range(9):
+        g.random_move(3, 0, mv)
+    a, b = azo.blokus_round_check(g, 60)
+    assert np.array_equal(a, b) and a.sum() == 60
+
+
+def test_search_with_the_tower_and_two_descents_per_round():
+    """The tower evaluates G * leaves positions per round; every simulation is accounted for and the root's priors are
+    the tower's softmax at the legal actions."""
+    from alphazero_amd import synth
+    G, budget, leaves = 12, 24, 2
+    Cs = synth.NETCONFIG2
+    dev = capi.Blokus(G, seed=9)
+    dev.search_config(max_budget=budget, leaves=leaves)
+    dev.playout(6)
+    dev.sync()
+    small = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    with pytest.raises(capi.AzError, match="evaluates 24 positions"):
+        dev.search_tower(small, budget)
+    tower = capi.Engine(20, 5, G * leaves, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    tower.load_weights(synth.make_blob(20, 5, Cs, 31, phead_gain=4.0, fc2_gain=2.0, c_out=91, value_dim=4))
+    dev.search_tower(tower, budget)
+    pol, _ = tower.tower_forward(np.concatenate([dev.boards(), dev.boards()]))
+    _, count = dev.legal_mask(want_mask=False)
+    for g in range(G):
+        r = dev.search_result(g)
+        assert r["root_n"] == budget + 1 and r["n"].sum() == budget and len(r["actions"]) == count[g]
+        assert np.array_equal(r["p"], pol[g, r["actions"]])
+    st = dev.search_stats()
+    assert st["restarts"] == 0 and st["rounds"] < budget + 2
+
+
 def test_search_at_config_size_2048_games_400_sims():
     """BASELINE configs[3]: 2048 concurrent games x 400 simulations (hash evaluator): every game's root holds
     exactly 400 visits spread over its legal actions, no tree outgrew its arena; a sample against the oracle."""
@@ -376,13 +477,23 @@ def _game_blocks(rows_planes, per_row):
     return blocks
 
 
-def test_selfplay_rows_match_the_oracle_bit_for_bit():
+@pytest.mark.parametrize("leaves", [1, 3])
+def test_selfplay_rows_match_the_oracle_bit_for_bit(leaves):
     """The move loop (search from a fresh root, row, sampled or arg-max move, step, reward hand-over, next game)
     on 3 games x 90 moves with the hash evaluator: every finished row -- planes, player to move, the visited
-    children's actions and n_child / n_root, the four-entry reward -- equals the oracle's loop, game by game."""
+    children's actions and n_child / n_root, the four-entry reward -- equals the oracle's loop, game by game; also
+    with three descents per round on both sides."""
     G, budget, n_moves, seed = 3, 6, 90, 11
     dev = capi.Blokus(G, seed=seed)
-    dev.search_config(max_budget=budget)
+    dev.search_config(max_budget=budget, leaves=leaves)
+    azo.blokus_set_leaves(leaves)
+    try:
+        _selfplay_rows_check(dev, G, budget, n_moves, seed)
+    finally:
+        azo.blokus_set_leaves(1)
+
+
+def _selfplay_rows_check(dev, G, budget, n_moves, seed):
     dev.selfplay_config(ring_rows=G * 2 * 84, max_budget=budget)
     dev.selfplay_moves(budget, n_moves)
     st = dev.selfplay_stats()
