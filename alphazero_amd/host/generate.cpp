@@ -38,7 +38,8 @@ int main(int argc, char const* argv[]) {
     const int games = g ? atoi(g) : 512;
 
     const std::vector<int> devices = az::parse_gpus(getenv("AZ_GPUS"), dev ? atoi(dev) : 0, az_device_count());
-    az::SelfPlay<Env> agent(games, iter_budget, 3, 3, devices[0], std::random_device{}(), 0, 0, devices);
+    az::SelfPlay<Env> agent(games, iter_budget, 3, 3, devices[0], std::random_device{}(), 0, 0, devices,
+                            az::parse_channels(getenv("AZ_NET_CHANNELS")));
     std::cout << "GPUs: " << devices.size() << " | games per GPU: " << games << std::endl;
     az::ReplayBuffer<Env> buffer(GEN, "*", port ? port : "5555");
     agent.load();

@@ -45,6 +45,34 @@ inline std::vector<int> parse_gpus(const char* spec, int fallback_device, int n_
     return d;
 }
 
+// "AZ_NET_CHANNELS": the tower's channel list as NetConfig::resblocks() would give it, "128x10" (ten entries of 128 =
+// NetConfig 2, the default when unset) or "256x21" (BASELINE's 20-block tower), or a comma-separated list.  The
+// reference's generator has NetConfig::get(2) compiled in (generate.cpp:58); this is how a trainer that was built with
+// another table is followed without recompiling.
+inline std::vector<int> parse_channels(const char* spec) {
+    if (!spec || !*spec) return NetConfig::get(2).resblocks();
+    const std::string s(spec);
+    std::vector<int> c;
+    const size_t x = s.find('x');
+    if (x != std::string::npos) {
+        const int ch = atoi(s.substr(0, x).c_str()), n = atoi(s.substr(x + 1).c_str());
+        if (ch < 1 || n < 2 || n > 64) throw Error("AZ_NET_CHANNELS: expected <channels>x<entries>, entries 2..64");
+        c.assign((size_t)n, ch);
+        return c;
+    }
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        const size_t q = s.find(',', pos);
+        const int ch = atoi(s.substr(pos, q == std::string::npos ? std::string::npos : q - pos).c_str());
+        if (ch < 1) throw Error("AZ_NET_CHANNELS: channel counts must be positive");
+        c.push_back(ch);
+        if (q == std::string::npos) break;
+        pos = q + 1;
+    }
+    if (c.size() < 2 || c.size() > 64) throw Error("AZ_NET_CHANNELS: 2..64 entries");
+    return c;
+}
+
 template <class Env>
 class SelfPlay {
 public:
@@ -53,10 +81,10 @@ public:
     // the others (az_group_load_weights).  With AZ_PAIR=1 in the environment run() is one launch of the persistent
     // tower / tree pair per call on every context that can (az_selfplay_run_pair), AZ_CHAIN=k lets simulations
     // that end in a stored terminal leaf ride along (az_selfplay_chain).
+    // `channels`: the tower (NetConfig::resblocks() form); empty = NetConfig::get(2), the reference's (generate.cpp:58).
     SelfPlay(int games, int iter_budget, float vl = 3, float c_puct = 3, int device = 0, uint64_t seed = 0,
-             int slot_base = 0, int contexts = 0, std::vector<int> devices = {})
-        : G(games), budget(iter_budget) {
-        const std::vector<int> Cs = NetConfig::get(2).resblocks();
+             int slot_base = 0, int contexts = 0, std::vector<int> devices = {}, std::vector<int> channels = {})
+        : G(games), budget(iter_budget), Cs(channels.empty() ? NetConfig::get(2).resblocks() : channels) {
         if (devices.empty()) devices = {device};
         if (contexts <= 0) { const char* e = getenv("AZ_CONTEXTS"); contexts = e ? atoi(e) : 1; }
         if (contexts < 1 || games < 2 * contexts || games % contexts) contexts = 1;
@@ -78,12 +106,13 @@ public:
     bool load() {
         WeightFile w;
         bool changed = false;
-        const std::string path = load_network(w, model_path, changed, [](WeightFile& f) {
-            f.N = Env::N; f.c_in = 3; f.c_out = 1; f.Cs = NetConfig::get(2).resblocks();
+        const std::vector<int>& cs = Cs;
+        const std::string path = load_network(w, model_path, changed, [&cs](WeightFile& f) {
+            f.N = Env::N; f.c_in = 3; f.c_out = 1; f.Cs = cs;
             f.blob = fresh_blob(Env::N, 3, f.Cs, 0);
         });
         if (changed) {
-            if (w.N != Env::N || w.Cs != NetConfig::get(2).resblocks()) throw Error("checkpoint shape does not match the environment");
+            if (w.N != Env::N || w.Cs != Cs) throw Error("checkpoint shape does not match the environment and the tower this generator was started with");
             check(az_group_load_weights(grp, w.blob.data(), w.blob.size()));
             model_path = path;
         }
@@ -129,6 +158,7 @@ public:
     int gpus() const { return n_gpus; }
     const std::string& model() const { return model_path; }
     const int G, budget;
+    const std::vector<int> Cs;
 private:
     az_group* grp = nullptr;
     int n_gpus = 1;

@@ -65,8 +65,11 @@ def test_checkpoint_swap_mid_run_goes_through_the_group_load_and_the_device_fold
         assert "cannot be read" in out.stdout and "Resuming with network model_1.pt" in out.stdout
 
 
+@pytest.mark.parametrize("channels", [None, "32x4"])
 @pytest.mark.skipif(find_libzmq() is None, reason="no libzmq for the PULL side")
-def test_generate_executable_streams_rows_to_a_pull_socket():
+def test_generate_executable_streams_rows_to_a_pull_socket(channels):
+    """channels: AZ_NET_CHANNELS, a tower other than the compiled-in NetConfig 2 (a fresh checkpoint of that shape is
+    written and read back like any other)."""
     exe = os.path.join(HOST, "generate")
     assert os.path.exists(exe)
     z = find_libzmq()
@@ -83,6 +86,8 @@ def test_generate_executable_streams_rows_to_a_pull_socket():
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "ckpt_location.txt"), "w").write("gen_0.pt")
         env = dict(os.environ, AZ_GAMES="32", AZ_PORT=str(port), AZ_SECONDS="60")
+        if channels:
+            env["AZ_NET_CHANNELS"] = channels
         proc = subprocess.Popen([exe, "1", "8", "0"], cwd=d, env=env, stdin=subprocess.PIPE,
                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         try:
