@@ -1874,8 +1874,11 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
     const int lane = tid & 63, wvi = tid >> 6, l31h = lane & 31, kh = lane >> 5;
     const int n_mb = MR / 32, n_units = (A + 31) / 32 * n_mb, n_slab = C_pad / 128;
     // the 256-byte run of (unit u, slab sl) this lane multiplies
-#define HEADS_XROW(u_, sl_) (x + ((size_t)(Gd + b * P + (min((u_) / n_mb * 32 + l31h, A - 1) / N) * W + min((u_) / n_mb * 32 + l31h, A - 1) % N)) * C_pad + (sl_) * 128 + kh * 64)
-#define HEADS_XLOAD(dst_, u_, sl_) do { const float* row_ = HEADS_XROW(u_, sl_); _Pragma("unroll") for (int q = 0; q < 16; ++q) dst_[q] = *(const f32x4h*)(row_ + 4 * q); } while (0)
+    // SPLIT: MFMA step s8 takes channels 16 s8 + 8 kh + j of the slab, so that the two k halves of a cell read adjacent
+    // 32-byte runs: a load instruction touches one 128-byte line per cell (32 per instruction) instead of two -- the
+    // kernel's time is the address unit's, which handles a line per cycle, more than the MFMAs' or HBM's.
+#define HEADS_XROW(u_, sl_) (x + ((size_t)(Gd + b * P + (min((u_) / n_mb * 32 + l31h, A - 1) / N) * W + min((u_) / n_mb * 32 + l31h, A - 1) % N)) * C_pad + (sl_) * 128 + kh * (SPLIT ? 8 : 64))
+#define HEADS_XLOAD(dst_, u_, sl_) do { const float* row_ = HEADS_XROW(u_, sl_); _Pragma("unroll") for (int q = 0; q < 16; ++q) dst_[q] = *(const f32x4h*)(row_ + (SPLIT ? 16 * (q >> 1) + 4 * (q & 1) : 4 * q)); } while (0)
     // (an empty statement that reads the sixteen registers: the wait for their loads lands here, not in front of the MFMAs)
 #define HEADS_XWAIT(r_) asm volatile("" :: "v"(r_[0]), "v"(r_[1]), "v"(r_[2]), "v"(r_[3]), "v"(r_[4]), "v"(r_[5]), "v"(r_[6]), "v"(r_[7]), \
                                      "v"(r_[8]), "v"(r_[9]), "v"(r_[10]), "v"(r_[11]), "v"(r_[12]), "v"(r_[13]), "v"(r_[14]), "v"(r_[15]))
@@ -1967,13 +1970,13 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
                 for (int q = 0; q < 16; ++q) xmax = fmaxf(fmaxf(xmax, fmaxf(xc[q].x, xc[q].y)), fmaxf(xc[q].z, xc[q].w));
             }
             if (SPLIT) {
-                // MFMA step s8 takes this lane's channels 64 kh + 8 s8 .. + 7 of the slab (k = 8 kh + j of the 32x32x16 form)
+                // MFMA step s8 takes this lane's channels 16 s8 + 8 kh .. + 7 of the slab (k = 8 kh + j of the 32x32x16 form)
                 typedef _Float16 h8s __attribute__((ext_vector_type(8)));
-                const unsigned char* whr = (const unsigned char*)s_wp + (size_t)(32 * mb + l31h) * RS + (sl * 128 + kh * 64) * 2;
+                const unsigned char* whr = (const unsigned char*)s_wp + (size_t)(32 * mb + l31h) * RS + (sl * 128 + kh * 8) * 2;
                 const unsigned char* wlr = whr + (size_t)MR * RS;
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
-                    const h8s wh = *(const h8s*)(whr + 16 * s8), wl = *(const h8s*)(wlr + 16 * s8);
+                    const h8s wh = *(const h8s*)(whr + 32 * s8), wl = *(const h8s*)(wlr + 32 * s8);
                     h8s xh, xl;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
