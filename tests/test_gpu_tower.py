@@ -441,3 +441,44 @@ def test_masked_policy_output_has_the_bits_of_the_dense_one():
     d, s_, m = dense.cpu().numpy(), sparse.cpu().numpy(), want.reshape(B, -1)
     assert m.sum() > 1000 and np.array_equal(s_[m], d[m]) and (s_[~m] == -5.0).all()
     assert np.array_equal(val.cpu().numpy(), val2.cpu().numpy())
+
+
+_FORMS = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from alphazero_amd import capi, synth
+z = np.load(%r)
+N, Cs, B = int(z["N"]), [int(c) for c in z["Cs"]], int(z["B"])
+c_in, c_out = (int(z["c_in"]), int(z["c_out"])) if "c_in" in z.files else (3, 1)
+eng = capi.Engine(N, min(N, 5), B, Cs=Cs, precision=capi.AZ_PREC_FP16X3, c_in=c_in, c_out=c_out, max_budget=1)
+eng.load_weights(synth.fixture_blob(z))
+pol, val = eng.tower_forward(z["boards"])
+np.savez(%r, pol=pol, val=val)
+"""
+
+
+@pytest.mark.parametrize("fixture", ["tower_n20_in5_out91.npz", "tower_n15_cfg2_spread.npz"])
+def test_fp16_pair_stem_and_heads_agree_with_the_fp32_mfma_forms(fixture, tmp_path, monkeypatch):
+    """The per-layer stem and heads on the 16-bit MFMAs with fp16-pair operands against the same kernels on the fp32
+    MFMAs (AZ_STEM_FP32 / AZ_HEADS_FP32, read once per process: one child process each), in the compensated mode,
+    where nothing behind the stem amplifies a last-bit difference: the outputs agree to 2e-6 and both hold the
+    reference fixture to 1e-4."""
+    import subprocess
+    import sys
+    monkeypatch.setenv("AZ_NO_FUSED", "1")
+    root = os.path.dirname(GOLDEN[:-len("/golden")])
+    path = os.path.join(GOLDEN, fixture)
+    outs = []
+    for tag, env in (("pair", {}), ("fp32", {"AZ_STEM_FP32": "1", "AZ_HEADS_FP32": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _FORMS % (root, path, out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(out))
+    z = np.load(path)
+    dp, dv = np.abs(outs[0]["pol"] - outs[1]["pol"]).max(), np.abs(outs[0]["val"] - outs[1]["val"]).max()
+    print(fixture, "pair vs fp32 forms: policy %.3g value %.3g" % (dp, dv))
+    assert dp < 2e-6 and dv < 2e-6
+    for o in outs:
+        assert np.abs(o["pol"] - z["policy"]).max() < 1e-4 and np.abs(o["val"] - z["value"]).max() < 1e-4
