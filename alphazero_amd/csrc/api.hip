@@ -106,7 +106,9 @@ struct az_ctx {
     // context's stream, the hand-over words, what the launches so far have published
     hipStream_t stream2 = nullptr;
     hipEvent_t pair_join = nullptr;                     // the tree kernel of the last pair launch has ended
-    unsigned pair_ticket = 0;
+    unsigned pair_started = 0;                          // tower workgroups launched by the pair launches so far
+    int pair_queue_attempts = 0;                        // streams tried until one ran side by side with the context's (0: none did)
+    bool other_work = false;                            // tower launches / lockstep rounds queued on the stream since the last pair launch
     AzPairDev pair = {};
     unsigned pair_base = 0;
     int n_cu = 0;
@@ -160,7 +162,43 @@ static size_t weights_size(int N, int c_in, int c_out, int vd, const int* Cs, in
     return s;
 }
 
+// Two kernels that wait for each other, one on each of two streams: does the GPU run the two side by side?  Kernel
+// `me` raises words[me], waits (at most `ticks` of the 100 MHz clock) for words[1 - me] and notes in words[2 + me]
+// whether it came (1) or not (2).  The persistent tower / tree pair needs exactly this of its two streams, and what
+// two streams get depends on the rest of the process: the runtime hands out four hardware queues per priority and
+// shares them out among all streams of that priority (two kernels in one in-order queue never overlap), and the command
+// processor serves a normal-priority queue that shares a pipe with a busy high-priority one only when that one idles.
+__global__ void az_queue_probe_kernel(unsigned* words, int me, unsigned ticks) {
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(words + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned r = 2u;
+    for (;;) {
+        if (__hip_atomic_load(words + 1 - me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { r = 1u; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)ticks) break;
+        __builtin_amdgcn_s_sleep(20);
+    }
+    __hip_atomic_store(words + 2 + me, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Both launch orders: the pair's tree kernel may start before the tower kernel or after it.
+static int queues_side_by_side(hipStream_t s1, hipStream_t s2, unsigned* words, bool* ok) {
+    *ok = true;
+    for (int order = 0; order < 2 && *ok; ++order) {
+        HIPCHK(hipMemsetAsync(words, 0, 16, s1));
+        HIPCHK(hipStreamSynchronize(s1));
+        hipLaunchKernelGGL(az_queue_probe_kernel, dim3(1), dim3(64), 0, order ? s2 : s1, words, order ? 1 : 0, 2000000u);   // 20 ms
+        hipLaunchKernelGGL(az_queue_probe_kernel, dim3(1), dim3(64), 0, order ? s1 : s2, words, order ? 0 : 1, 2000000u);
+        HIPCHK(hipStreamSynchronize(s1));
+        HIPCHK(hipStreamSynchronize(s2));
+        unsigned h[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(h, words, 16, hipMemcpyDeviceToHost));
+        *ok = h[2] == 1u && h[3] == 1u;
+    }
+    return AZ_OK;
+}
+
 static int ctx_build(az_ctx* c, const az_config* cfg);
+static int pair_warm_up(az_ctx* c);
 
 extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
     if (!out || !cfg) return fail(AZ_E_ARG, "null argument");
@@ -262,20 +300,35 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         HIPCHK(hipMemcpy(d.noise, nz.data(), nz.size() * 4, hipMemcpyHostToDevice));
     }
     AZCHK(dalloc(c, &c->pair.plane_seq, S)); AZCHK(dalloc(c, &c->pair.eval_seq, S));
-    AZCHK(dalloc(c, &c->pair.abort, 4)); AZCHK(dalloc(c, &c->pair.start, 4)); AZCHK(dalloc(c, &c->pair.busy, G));
+    AZCHK(dalloc(c, &c->pair.abort, 8)); AZCHK(dalloc(c, &c->pair.start, 4)); AZCHK(dalloc(c, &c->pair.busy, G));
     c->pair.plane_stride = (3 * A + 15) / 16 * 16;
     AZCHK(dalloc(c, &c->pair.planes_wt, S * (size_t)(c->pair.plane_stride / 4)));
-    {
+    if (cfg->eval_mode == AZ_EVAL_TOWER) {
         // The pair's tree kernel gets a stream of its own, made here and not at the first pair launch: making a stream
         // makes a hardware queue, for which the driver takes every queue of the process off the GPU and puts it back --
-        // running kernels are saved and restored, and a pair of another context that is saved in the middle of a launch
-        // need not come back with both kernels resident.  It is a high-priority stream: the runtime keeps a pool of
-        // hardware queues per priority (four each), so it can never land on the hardware queue that carries the
-        // context's own stream -- two kernels that wait for each other in one in-order queue would never both start.
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
+        // running kernels are saved and restored in the middle of another context's launch.  Which stream: one on which
+        // a kernel runs side by side with a kernel on the context's stream, found by trying (queues_side_by_side); the
+        // runtime shares four hardware queues out among the streams of a priority, and two kernels in one in-order
+        // queue never overlap.  The streams that failed are kept until the search is over, so that the runtime hands
+        // the next one another queue.  Same priority as the context's stream, on purpose: the command processor serves
+        // a normal-priority queue that shares a pipe with a busy high-priority one only when that one idles, and which
+        // queues share a pipe changes with every queue the process makes -- with the tree kernel on a high-priority
+        // stream, pairs that had passed this test at creation later ran one kernel at a time until the time-out.
+        // No such stream: the context plays lockstep rounds only (az_selfplay_run_pair says why).
         HIPCHK(hipEventCreateWithFlags(&c->pair_join, hipEventDisableTiming));
+        std::vector<hipStream_t> failed;
+        const bool no_probe = getenv("AZ_PAIR_NO_QUEUE_PROBE") != nullptr;          // (queue experiments)
+        for (int attempt = 0; attempt < 8 && !c->stream2; ++attempt) {
+            hipStream_t s2 = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            bool ok = true;
+            const int rc = no_probe ? (int)AZ_OK : queues_side_by_side(c->stream, s2, c->pair.start, &ok);
+            if (rc != AZ_OK) { (void)hipStreamDestroy(s2); for (hipStream_t f : failed) (void)hipStreamDestroy(f); return rc; }
+            if (ok) { c->stream2 = s2; c->pair_queue_attempts = attempt + 1; }
+            else failed.push_back(s2);
+        }
+        for (hipStream_t f : failed) (void)hipStreamDestroy(f);
+        HIPCHK(hipMemset(c->pair.start, 0, 16));
     }
     {
         hipDeviceProp_t prop;
@@ -342,6 +395,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         if (az_tower_configure() != 0) return fail(AZ_E_HIP, "tower kernel LDS configuration failed");
     }
     HIPCHK(hipDeviceSynchronize());
+    AZCHK(pair_warm_up(c));
     return AZ_OK;
 }
 
@@ -493,6 +547,7 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
                         unsigned short* actX, unsigned short* actH, float* actR, unsigned short* actL, bool sampled,
                         const unsigned* mask = nullptr) {
     const int N = c->cfg.N, Cp = c->C_pad, Gd = c->Gd, M = B * c->P;
+    c->other_work = true;
     if (c->fused) {
         const bool on = prof_begin(c, 0, sampled, c->stream);
         az_launch_tower_fused(c->stream, c->prec, planes_dev, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
@@ -971,7 +1026,7 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
     HIPCHK(hipMemsetAsync(c->d.g_hw_nodes, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.g_hw_edges, 0, sizeof(int) * c->cfg.G, c->stream));
     HIPCHK(hipMemsetAsync(c->d.err, 0, sizeof(int) * c->cfg.G, c->stream));
-    HIPCHK(hipMemsetAsync(c->pair.abort, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->pair.abort, 0, 32, c->stream));
     HIPCHK(hipMemsetAsync(c->pair.busy, 0, sizeof(unsigned long long) * c->cfg.G, c->stream));
     c->pair_launches = 0; c->pair_rounds = 0;
     az_launch_selfplay_begin(c->stream, &c->d);
@@ -987,20 +1042,44 @@ extern "C" int az_selfplay_begin(az_ctx* c, int budget) {
 static const char* pair_unfit(const az_ctx* c) {
     if (c->cfg.eval_mode != AZ_EVAL_TOWER || !c->fused) return "the tower does not run as one launch per evaluation";
     if (c->d.L != 1) return "leaves_per_round > 1";
-    if (az_tower_fused_lds_bytes(c->cfg.N, 2 * c->num_res, 256) + 64 + AZ_TREE_SMEM_BYTES > 160 * 1024)
+    if (!c->stream2) return "no second stream of this process runs side by side with the context's (hardware queues shared with or starved by other streams)";
+    if (az_tower_fused_lds_bytes(c->cfg.N, 2 * c->num_res, 256) + 64 + (size_t)az_tree_smem_bytes(c->A) > 160 * 1024)
         return "no LDS left on a CU for a tree wave beside the tower's workgroup";
     return nullptr;
+}
+
+// Both kernels of the pair once with no rounds, on their streams, while nothing else runs: both spill a few registers,
+// and the first kernel with a private segment on a hardware queue makes the runtime set that queue's scratch memory up
+// in the middle of the dispatch.  Left to the first real launch, that happened with the tower workgroups already
+// spinning on the CUs, and once in a few process starts the launch then ran into its time-out.
+static int pair_warm_up(az_ctx* c) {
+    if (c->tower_only || pair_unfit(c)) return AZ_OK;
+    AzPairDev pr = c->pair;
+    pr.base = 0; pr.rounds = 0; pr.timeout_ticks = 1000u; pr.flags = 0u; pr.started_want = 0u;
+    const int blocks = az_launch_tower_pair(c->stream, c->prec, (const uint8_t*)c->pair.planes_wt, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
+                                            c->head_pt, c->d.policy, c->d.value, c->cfg.G, c->cfg.N, c->Gd, 2 * c->num_res,
+                                            c->d_sat, &pr, c->n_cu);
+    if (blocks > 0) c->pair_started += (unsigned)blocks;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    pr.started_want = c->pair_started;
+    az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemset(c->pair.abort, 0, 32));
+    return AZ_OK;
 }
 
 // A wait of the pair that ran out (the two kernels were not resident together): sticky, reported by every later call.
 static int pair_check(az_ctx* c) {
     if (!c->pair_launches) return AZ_OK;
-    unsigned ab[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(ab, c->pair.abort, 16, hipMemcpyDeviceToHost));
-    if (ab[0]) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out (the %s of game %u wanted word %u and saw %u): "
+    unsigned ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpy(ab, c->pair.abort, 32, hipMemcpyDeviceToHost));
+    if (ab[0]) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out (the %s of game %u wanted word %u and saw %u; waits saw the clock step %u times: "
+                                        "that often the waves were taken off the GPU and put back): "
                                         "the two kernels were not resident together (another process on this GPU, or a profiler that "
                                         "serialises launches); the games of this context are no longer in step -- run such set-ups with "
-                                        "az_selfplay_run", (ab[1] >> 31) ? "tree wave" : "tower workgroup", ab[1] & 0x7FFFFFFFu, ab[2], ab[3]);
+                                        "az_selfplay_run", ab[1] == 0xC0000000u ? "gate in front of the tree kernel, waiting for the tower workgroups to begin; not a wait" : (ab[1] >> 31) ? "tree wave" : "tower workgroup",
+                                        ab[1] & 0x3FFFFFFFu, ab[2], ab[3], ab[4]);
     return AZ_OK;
 }
 
@@ -1030,16 +1109,24 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     const char* dbg_s = getenv("AZ_PAIR_FLAGS");
     const int dbg = dbg_s ? atoi(dbg_s) : 0;
     pr.flags = (unsigned)(dbg & 3);
-    pr.ticket = ++c->pair_ticket;
+    // The gate in front of the tree kernel runs as soon as the last pair launch's tree waves have left and gives the
+    // tower kernel one time-out to begin: a launch goes behind another pair launch of the context or onto an idle
+    // stream, never behind evaluations or lockstep rounds that are still running (the host waits for those; mixing
+    // the two forms is rare).
+    if (c->other_work) {
+        if (hipStreamQuery(c->stream) == hipErrorNotReady) HIPCHK(hipStreamSynchronize(c->stream));
+        c->other_work = false;
+    }
     const int dev = c->cfg.device;
     std::unique_lock<std::mutex> pair_lk(g_pair_mu[dev < AZ_MAX_DEVICES ? dev : 0]);
     // A pair wants every CU: a second pair on the GPU at the same time would leave neither resident.  The pair launches
     // of the contexts of this process on one GPU take turns, and it is the host that waits for the other context's
-    // launch to finish: a wait on the GPU (hipStreamWaitEvent) leaves a blocked barrier packet at the head of this
-    // context's high-priority hardware queue for as long as the other pair runs, and the command processor then no
-    // longer serves a normal-priority queue that shares its pipe -- the other context's own stream, which never gets
-    // to signal the event.  For the same reason the tree kernel's stream waits for nothing of the context's stream
-    // here: the tree waves wait in the kernel for the tower kernel's start word instead.
+    // launch to finish: a wait on the GPU (hipStreamWaitEvent) leaves blocked barrier packets at the heads of this
+    // context's hardware queues for as long as the other pair runs, and a blocked packet on a queue of higher
+    // priority stops the command processor from serving a queue that shares its pipe -- when the tree kernel's
+    // stream was a high-priority one that was the other context's own stream, which then never signalled the event.
+    // The streams have one priority now; the tree kernel's stream still waits for no event of the context's stream:
+    // the gate kernel in front of the tree kernel waits in memory for the tower workgroups instead.
     if (dev < AZ_MAX_DEVICES) {
         if (!g_pair_done[dev]) HIPCHK(hipEventCreateWithFlags(&g_pair_done[dev], hipEventDisableTiming));
         else if (g_pair_last[dev] != c) HIPCHK(hipEventSynchronize(g_pair_done[dev]));
@@ -1055,6 +1142,8 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
                                             c->d_sat, &pr, c->n_cu);
     if (blocks <= 0) return fail(AZ_E_STATE, "az_selfplay_run_pair: the persistent tower kernel does not fit");
     if (sampled) { (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream); c->prof_used += 2; }
+    c->pair_started += (unsigned)blocks;
+    pr.started_want = c->pair_started;
     if (!(dbg & 4)) az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
     // the context's stream goes on behind both kernels (a normal-priority queue may wait for a high-priority one)
     HIPCHK(hipEventRecord(c->pair_join, c->stream2));

@@ -115,9 +115,12 @@ struct AzTreeDev {
 //                                planes_wt with write-through stores, publishes plane_seq[g] = base + i + 1
 //   tower workgroup, tile t    : waits plane_seq[g] >= base + i for its boards (i = 1: ready before the launch),
 //                                evaluates, publishes eval_seq[g] = base + i
-// The tree kernel's stream does not wait for the tower kernel's stream: the tower kernel stores the launch's ticket
-// to start[0] when it begins (everything queued ahead of it on the context's stream has finished by then), and the
-// tree waves wait for that word before they touch a game.
+// The tree kernel's stream does not wait for the tower kernel's stream.  Every tower workgroup counts itself in
+// start[1] when it begins (everything queued ahead of the tower kernel on the context's stream has finished by then),
+// and a one-wave gate kernel in front of the tree kernel, on the tree kernel's stream, waits until all of them have:
+// the tree waves are handed out only when every CU already holds its tower workgroup, which leaves room for exactly
+// one tree wave per CU.  (Handed out first, onto a chip that a copy kernel is still leaving, two tree waves may land
+// on one CU; the tower workgroup of that CU then never fits, and both kernels wait until the time-out.)
 // A wait that lasts longer than timeout_ticks (the two kernels are not resident together) raises abort[0]; every
 // wave of both kernels then leaves at its next wait, so the grids always drain.
 struct AzPairDev {
@@ -125,9 +128,9 @@ struct AzPairDev {
     unsigned* eval_seq;             // [G]
     unsigned* planes_wt;            // [G][plane_stride / 4] the planes once more, as whole words stored write-through
     int       plane_stride;         // bytes per game in planes_wt: 3 A rounded up to 16
-    unsigned* abort;                // [4] [0] raised by a wait that ran out, [1..3] that wait's notes
-    unsigned* start;                // [4] [0] ticket of the last launch whose tower kernel has begun
-    unsigned  ticket;               // this launch's
+    unsigned* abort;                // [8] [0] raised by a wait that ran out, [1..3] that wait's notes, [4] clock steps seen by waits
+    unsigned* start;                // [4] [1] tower workgroups that have begun, over all launches so far
+    unsigned  started_want;         // ... once every workgroup of this launch has
     unsigned long long* busy;       // [G] 100 MHz ticks the tree wave worked on the game (waits excluded)
     unsigned  base;                 // evaluations of every game published by earlier launches
     int       rounds;
@@ -146,14 +149,24 @@ __device__ __forceinline__ unsigned az_pair_peek(const unsigned* w) {
 template <int SLEEP>
 __device__ inline bool az_pair_wait(const unsigned* w, unsigned want, unsigned* abort, unsigned long long limit, unsigned tag) {
     if ((int)(az_pair_peek(w) - want) >= 0) return true;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), tp = t0;
     for (;;) {
         __builtin_amdgcn_s_sleep(SLEEP);
         const unsigned seen = az_pair_peek(w);
         if ((int)(seen - want) >= 0) return true;
         if (az_pair_peek(abort) != 0u) return false;
-        // signed: a wave that was saved and restored elsewhere may read a counter a few ticks behind its first reading
-        if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > (long long)limit) {
+        // The clock between two polls (microseconds apart) does not count when it stepped back or forward by more than
+        // 0.1 s: the wave was taken off the GPU and put back in between (the driver does that to every queue of the
+        // process whenever the process makes or drops a hardware queue -- a new stream, the first copy on a DMA
+        // engine), during which its partner did not run either, and it may be reading another die's counter now.
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        const long long step = (long long)(now - tp);
+        if (step < 0 || step > 10000000ll) {
+            t0 += (unsigned long long)step;
+            __hip_atomic_fetch_add(abort + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tallied for the error text
+        }
+        tp = now;
+        if ((long long)(now - t0) > (long long)limit) {
             __hip_atomic_store(abort + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(abort + 2, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(abort + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -2,8 +2,9 @@
 #pragma once
 #include "az_dev.h"
 
-// dynamic LDS of a tree block (board bytes + per-descent records)
+// dynamic LDS of a tree block (board bytes + per-descent records): at most, and for a board of A cells
 #define AZ_TREE_SMEM_BYTES (512 + 4 * 448 * 4)
+static inline int az_tree_smem_bytes(int A) { return ((A + 15) & ~15) + 4 * ((A + 1 + 7) & ~7) * 4; }
 
 extern "C" {
 int  az_tree_configure(const AzTreeDev* d);

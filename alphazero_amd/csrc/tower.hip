@@ -1754,8 +1754,8 @@ az_tower_pair_kernel(AzTowerPairArgs) {
     KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const int rounds = ka->pr.rounds, tiles = ka->tiles;
     __builtin_amdgcn_s_setprio(3);                                       // ahead of the tree wave that shares this SIMD
-    if (blockIdx.x == 0 && threadIdx.x == 0)                             // the tree waves of this launch may go
-        __hip_atomic_store(ka->pr.start, ka->pr.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0)                                                // this CU has its tower workgroup (the tree kernel's gate counts)
+        __hip_atomic_fetch_add(ka->pr.start + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) s_go = 0;                                      // 0: wait for the tile's planes, 1: already acquired, -1: leave
     __syncthreads();
     bool warm = false;

@@ -26,10 +26,15 @@ extern "C" int az_tree_timing_read(unsigned long long* out) {
 #define TTS(slot_) do {} while (0)
 #endif
 #define AZ_CELLS_MAX 512
-// LDS of a tree block: board bytes, then per-descent records (old n, old v, action, edge): 7.5 KB,
-// small enough to sit on a CU beside a resident tower workgroup
+// LDS of a tree block: board bytes, then per-descent records (old n, old v, action, edge), sized by the board: the
+// records hold A + 1 plies at most.  7.5 KB at 21x21; 3.9 KB at 15x15, where a CU holds two such blocks beside a
+// resident tower workgroup (8 KB are left): should two tree waves of the persistent pair ever land on one CU -- the
+// driver takes the waves of a process off the GPU and puts them back, in any order, whenever the process makes or
+// drops a hardware queue -- the tower workgroup of that CU still fits.
 #define AZ_PATH_MAX 448          // plies of one descent: A + 1 <= 442
-#define AZ_SMEM_FIXED (AZ_CELLS_MAX + 4 * AZ_PATH_MAX * 4)
+__host__ __device__ __forceinline__ int az_smem_cells(int A) { return (A + 15) & ~15; }
+__host__ __device__ __forceinline__ int az_smem_plies(int A) { return (A + 1 + 7) & ~7; }
+__host__ __device__ __forceinline__ int az_smem_bytes(int A) { return az_smem_cells(A) + 4 * az_smem_plies(A) * 4; }
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // phase clocks of the verbosity-3 report (mcts.hpp:187-201,248-303): read only while the context asks for them
@@ -335,9 +340,10 @@ __device__ int az_select(const AzTreeDev& d, int g, int k, uint8_t* s_cells, int
     // per-ply records of this descent, all in LDS: while descending the wave issues loads only;
     // the virtual-loss updates and the path go to HBM in one parallel batch at the end
     int* s_old_n = s_old;
-    float* s_old_v = (float*)(s_old + AZ_PATH_MAX);
-    int* s_act = s_old + 2 * AZ_PATH_MAX;
-    int* s_path = s_old + 3 * AZ_PATH_MAX;
+    const int pm = az_smem_plies(A);
+    float* s_old_v = (float*)(s_old + pm);
+    int* s_act = s_old + 2 * pm;
+    int* s_path = s_old + 3 * pm;
     const int ar = uni(d.arena[g]);
     AzEdge* E = d.edges[ar] + (size_t)g * d.edge_cap;
     const uint16_t* EA = d.eact[ar] + (size_t)g * d.edge_cap;
@@ -622,7 +628,7 @@ __device__ void az_selfplay_move(const AzTreeDev& d, int g, uint8_t* s_cells) {
 // bit1: advance (finish search / play move / select the next leaf).
 __device__ __forceinline__ void az_round_once(const AzTreeDev& d, int phase_mask, int mode, int g, unsigned char* smem) {
     uint8_t* s_cells = smem;
-    int* s_old = (int*)(smem + AZ_CELLS_MAX);
+    int* s_old = (int*)(smem + az_smem_cells(d.A));
     TTS(0);
     if (uni(d.status[g]) != AZ_ST_RUN) return;
     TTS(1);
@@ -631,7 +637,7 @@ __device__ __forceinline__ void az_round_once(const AzTreeDev& d, int phase_mask
     TTS(2);
     if (phase_mask & 1)
         for (int k = 0; k < d.L; ++k) {
-            az_apply(d, g, k, s_cells, s_old + 2 * AZ_PATH_MAX);
+            az_apply(d, g, k, s_cells, s_old + 2 * az_smem_plies(d.A));
             if (uni(d.status[g]) != AZ_ST_RUN) return;
         }
     TTS(3);
@@ -700,13 +706,6 @@ az_round_pair_kernel(AzTreeDev, AzPairDev pr, int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AzTreeArgs ka = (AzTreeArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const int G = ka->G;
-    {
-        // Nothing of this launch before the tower kernel of this launch has begun: it sits behind whatever else the
-        // context's stream holds (rounds launched one by one, a weight load), which may take long -- a bound of its
-        // own, 150 hand-over time-outs (ten minutes by default), so that the grid drains whatever happens.
-        const bool ok = az_pair_wait<100>(pr.start, pr.ticket, pr.abort, 150ull * pr.timeout_ticks, 0xC0000000u);
-        if (__ballot(!ok) != 0ull) return;
-    }
     for (int i = 1; i <= pr.rounds; ++i) {
         const unsigned want = pr.base + (unsigned)i;
         for (int g = blockIdx.x; g < G; g += gridDim.x) {
@@ -870,14 +869,20 @@ az_eval_hash_kernel(const uint8_t* planes, float* policy, float* value, int A) {
 // ------------------------------------------------------------ host launchers
 #include "az_tree.h"
 
-static inline size_t tree_smem(const AzTreeDev&) { return AZ_SMEM_FIXED; }
-static_assert(AZ_SMEM_FIXED == AZ_TREE_SMEM_BYTES, "az_tree.h states the tree block's LDS");
+static inline size_t tree_smem(const AzTreeDev& d) { return (size_t)az_smem_bytes(d.A); }
+static_assert(16 * ((21 * 21 + 15) / 16) + 4 * 448 * 4 <= AZ_TREE_SMEM_BYTES, "az_tree.h states the tree block's largest LDS");
 
 extern "C" int az_tree_configure(const AzTreeDev*) { return 0; }
 extern "C" void az_launch_round(hipStream_t s, const AzTreeDev* d, int phase_mask, int mode, int g0, int count) {
     hipLaunchKernelGGL(az_round_kernel, dim3(count), dim3(AZ_WAVE), tree_smem(*d), s, *d, phase_mask, mode, g0);
 }
+// One wave in front of the tree kernel on its stream: ends when every tower workgroup of the launch has begun (or the
+// wait runs out: the tree waves then find the abort word raised and leave at once).
+extern "C" __global__ void __launch_bounds__(AZ_WAVE) az_pair_gate_kernel(AzPairDev pr) {
+    if (threadIdx.x == 0) (void)az_pair_wait<20>(pr.start + 1, pr.started_want, pr.abort, pr.timeout_ticks, 0xC0000000u);
+}
 extern "C" void az_launch_round_pair(hipStream_t s, const AzTreeDev* d, const AzPairDev* pr, int mode, int blocks) {
+    hipLaunchKernelGGL(az_pair_gate_kernel, dim3(1), dim3(AZ_WAVE), 0, s, *pr);
     hipLaunchKernelGGL(az_round_pair_kernel, dim3(blocks), dim3(AZ_WAVE), tree_smem(*d), s, *d, *pr, mode);
 }
 extern "C" void az_launch_begin(hipStream_t s, const AzTreeDev* d, int budget) {

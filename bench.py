@@ -334,8 +334,8 @@ def main():
                     e.selfplay_run(k)
                 done += k
 
-        def barrier():
-            for e in es:
+        def barrier(engines=True):
+            for e in (es if engines else []):
                 e.sync()
             torch.cuda.synchronize()
             if use_dist:
@@ -372,9 +372,28 @@ def main():
         barrier()
         st0 = agg([e.stats() for e in es])
         t0 = time.perf_counter()
-        run(steps * rps)
-        barrier()
+        # (a pair that stops being resident together in the timed region -- another process arriving on the GPU --
+        # ends the leg the same way as one that never was: every rank leaves together, the lockstep form takes over)
+        ok, why = 1, ""
+        try:
+            run(steps * rps)
+            for e in es:
+                e.sync()
+        except capi.AzError as ex:
+            if not pair:
+                raise
+            ok, why = 0, str(ex)
+        barrier(engines=bool(ok))
         el = time.perf_counter() - t0
+        if use_dist and pair:
+            t = torch.tensor([ok], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0 and ok:
+                ok, why = 0, "another rank's persistent pair did not run"
+        if not ok:
+            for e in es:
+                e.close()
+            return {"error": why}
         st = agg([e.stats() for e in es])
         leg = {"pair": pair, "chain": chain, "steps": steps, "engs": es, "run": run, "el_local": el, "el": el, "every": every, "st": st,
                "sims_local": st["sims_backed_up"] - st0["sims_backed_up"],

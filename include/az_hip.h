@@ -244,9 +244,12 @@ int az_selfplay_chain(az_ctx*, int max_chained);
  * The error text names the wait that ran out (tower workgroup or tree wave, game, the word it wanted and saw).
  * The call returns once the launch is queued, like az_selfplay_run, with one exception: when the last pair launch on
  * this GPU was another context's of this process, it first waits on the host for that launch to end (two pairs at
- * once would leave neither resident; see api.hip for why the wait is not left to the GPU).  Work queued on the
- * context's stream ahead of the launch must end within 150 time-outs (ten minutes by default): the tree waves are
- * resident by then and give up after that.
+ * once would leave neither resident; see api.hip for why the wait is not left to the GPU), and when evaluations or
+ * lockstep rounds of this context are still running it waits for those (the tree waves of a launch are resident at
+ * once and give the tower kernel one time-out to begin).  The two kernels run on two streams of the context, of
+ * the same priority and on different hardware queues (tried out when the context is made: a process whose other
+ * streams leave no such queue gets AZ_E_STATE here and plays lockstep rounds); work of OTHER streams that shares
+ * those queues and runs for seconds can still hold one of the two kernels up until the time-out.
  * With AZ_PAIR=1 in the environment az_selfplay_run takes this path whenever the context can. */
 int az_selfplay_run_pair(az_ctx*, int rounds);
 /* What the pair launches since az_profile_enable / az_selfplay_begin took: mean duration of the sampled tower

@@ -176,9 +176,9 @@ def test_pair_launches_of_two_contexts_on_one_gpu_take_turns():
         for _ in range(3):
             a.selfplay_run_pair(rounds // 3)
             b.selfplay_run_pair(rounds // 3)
-        ref.selfplay_run(rounds)
         a.sync()
         b.sync()
+        ref.selfplay_run(rounds)
         ref.sync()
         assert b.stats() == ref.stats()
         assert a.stats()["sims_backed_up"] == ref.stats()["sims_backed_up"]
