@@ -1107,7 +1107,11 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     // timing experiments (wrong games with bit 0 or 2): 1 = the tower never waits, 2 = no early look at the next tile's
     // words, 4 = no tree kernel (with 1: the tower alone; without: the tower's first wait runs out, the drain path)
     const char* dbg_s = getenv("AZ_PAIR_FLAGS");
-    const int dbg = dbg_s ? atoi(dbg_s) : 0;
+    int dbg = dbg_s ? atoi(dbg_s) : 0;
+    {   // AZ_PAIR_FAIL_AFTER=n (tests of the callers' recovery): the context's launch number n goes out without its tree kernel
+        static const char* fa = getenv("AZ_PAIR_FAIL_AFTER");
+        if (fa && c->pair_launches == atoll(fa)) dbg |= 4;
+    }
     pr.flags = (unsigned)(dbg & 3);
     // The gate in front of the tree kernel runs as soon as the last pair launch's tree waves have left and gives the
     // tower kernel one time-out to begin: a launch goes behind another pair launch of the context or onto an idle
@@ -1241,6 +1245,7 @@ extern "C" int az_replay_drain(az_ctx* c, int cap, uint8_t* cells, uint8_t* to_m
     if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    AZCHK(pair_check(c));                                    // rows of a pair that fell out of step are nobody's games
     const size_t A = c->A;
     const int n0 = drain_ring(c, c->active ^ 1, cap, cells, to_move, policy, reward);
     if (n0 < 0 || n0 == cap) return n0;
@@ -1270,6 +1275,7 @@ extern "C" int az_replay_drain_retired(az_ctx* c, int cap, uint8_t* cells, uint8
     if (cap > 0) { NEED(cells); NEED(to_move); NEED(policy); NEED(reward); }
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipEventSynchronize(c->flip_ev));                 // never recorded (no flip yet): returns at once, the ring is empty
+    AZCHK(pair_check(c));                                    // rows of a pair that fell out of step are nobody's games
     return drain_ring(c, c->active ^ 1, cap, cells, to_move, policy, reward);
 }
 

@@ -75,12 +75,23 @@ int main(int argc, char const* argv[]) {
     const bool overlap = getenv("AZ_NO_OVERLAP") == nullptr;
     agent.run(iter_budget);                       // about one move per slot
     while (alive) {
-        if (overlap) {
-            agent.flip();                         // rows of the rounds queued so far: the retired rings
-            agent.run(iter_budget);               // the next move, queued behind them
-            rows += agent.drain_retired(emit);    // waits for the retired rounds only
-        } else {
-            rows += agent.drain(emit);
+        try {
+            if (overlap) {
+                agent.flip();                     // rows of the rounds queued so far: the retired rings
+                agent.run(iter_budget);           // the next move, queued behind them
+                rows += agent.drain_retired(emit);    // waits for the retired rounds only
+            } else {
+                rows += agent.drain(emit);
+                agent.run(iter_budget);
+            }
+        } catch (const az::Error& e) {
+            // A pair that stops being resident together in the middle of a run (another process arriving on the GPU)
+            // leaves its games out of step: start them again as lockstep rounds and go on producing.
+            if (!pair || std::string(e.what()).find("hand-over wait") == std::string::npos) throw;
+            std::cout << "The persistent tower / tree pair stopped running (" << e.what() << "); games restarted as lockstep rounds." << std::endl;
+            setenv("AZ_PAIR", "0", 1);
+            pair = false;
+            agent.begin();
             agent.run(iter_budget);
         }
         agent.load();                             // agent.load() per game start in the reference (generate.cpp:73)

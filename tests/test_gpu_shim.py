@@ -65,11 +65,13 @@ def test_checkpoint_swap_mid_run_goes_through_the_group_load_and_the_device_fold
         assert "cannot be read" in out.stdout and "Resuming with network model_1.pt" in out.stdout
 
 
-@pytest.mark.parametrize("channels", [None, "32x4"])
+@pytest.mark.parametrize("channels,fail_after", [(None, None), ("32x4", None), (None, 2)])
 @pytest.mark.skipif(find_libzmq() is None, reason="no libzmq for the PULL side")
-def test_generate_executable_streams_rows_to_a_pull_socket(channels):
+def test_generate_executable_streams_rows_to_a_pull_socket(channels, fail_after):
     """channels: AZ_NET_CHANNELS, a tower other than the compiled-in NetConfig 2 (a fresh checkpoint of that shape is
-    written and read back like any other)."""
+    written and read back like any other).  fail_after: the persistent pair loses its tree kernel at that launch
+    (AZ_PAIR_FAIL_AFTER, a 50 ms time-out): the producer says so, restarts its games as lockstep rounds and keeps
+    streaming."""
     exe = os.path.join(HOST, "generate")
     assert os.path.exists(exe)
     z = find_libzmq()
@@ -88,8 +90,11 @@ def test_generate_executable_streams_rows_to_a_pull_socket(channels):
         env = dict(os.environ, AZ_GAMES="32", AZ_PORT=str(port), AZ_SECONDS="60")
         if channels:
             env["AZ_NET_CHANNELS"] = channels
+        if fail_after is not None:
+            env.update(AZ_PAIR_FAIL_AFTER=str(fail_after), AZ_PAIR_TIMEOUT_MS="50")
+        log = open(os.path.join(d, "generate.out"), "w")
         proc = subprocess.Popen([exe, "1", "8", "0"], cwd=d, env=env, stdin=subprocess.PIPE,
-                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                                stdout=log, stderr=subprocess.PIPE)
         try:
             ctx = z.zmq_ctx_new()
             sock = z.zmq_socket(ctx, ZMQ_PULL)
@@ -125,3 +130,9 @@ def test_generate_executable_streams_rows_to_a_pull_socket(channels):
                 proc.wait(timeout=30)
             except subprocess.TimeoutExpired:
                 proc.kill()
+            log.close()
+        out = open(os.path.join(d, "generate.out")).read()
+        if fail_after is not None:
+            assert "games restarted as lockstep rounds" in out, out[-2000:]
+        else:
+            assert "lockstep rounds" not in out, out[-2000:]
