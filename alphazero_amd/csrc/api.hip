@@ -1149,7 +1149,7 @@ extern "C" int az_selfplay_run_pair(az_ctx* c, int rounds) {
     c->pair_started += (unsigned)blocks;
     pr.started_want = c->pair_started;
     if (!(dbg & 4)) az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
-    // the context's stream goes on behind both kernels (a normal-priority queue may wait for a high-priority one)
+    // the context's stream goes on behind both kernels
     HIPCHK(hipEventRecord(c->pair_join, c->stream2));
     HIPCHK(hipStreamWaitEvent(c->stream, c->pair_join, 0));
     if (dev < AZ_MAX_DEVICES) HIPCHK(hipEventRecord(g_pair_done[dev], c->stream));

@@ -247,20 +247,26 @@ template <int PR, int CIN>
 __global__ void __launch_bounds__(256, 2)
 az_stem_split_kernel(const uint8_t* __restrict__ planes, unsigned short* __restrict__ out, float* __restrict__ out32,
                      unsigned short* __restrict__ out_lo /* non-null: the stream as out + out_lo instead of out32 */,
-                     const float* __restrict__ w, const float* __restrict__ bias, int N, int C_pad, int Gd) {
+                     const float* __restrict__ w, const float* __restrict__ bias, int N, int C_pad, int Gd,
+                     int B, int bpb /* boards per block: the blocks of 32 positions of all of them are dealt out to the four
+                                       waves in turn (14 blocks of a 20x20 board alone leave two waves a block short), and
+                                       the weight image is built once for all of them */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr int KW = CIN * 9, KS = (KW + 15) / 16;
     const int A = N * N, W = N + 1, P = W * W;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int SI = (CIN * A + 15) & ~15;             // bytes of one board's planes in LDS
+    const int b0 = blockIdx.x * bpb, nb = min(bpb, B - b0), tid = threadIdx.x;
     const int lane = tid & 63, wvi = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     float* s_bs = (float*)smem;                      // [C_pad]
-    uint8_t* s_in = smem + C_pad * 4;                // [CIN][A]
-    unsigned char* stage = smem + C_pad * 4 + ((CIN * A + 15) & ~15) + wvi * 32 * STEM_SROW;
+    uint8_t* s_in0 = smem + C_pad * 4;               // [bpb][CIN][A]
+    unsigned char* stage = smem + C_pad * 4 + bpb * SI + wvi * 32 * STEM_SROW;
     for (int i = tid; i < C_pad; i += 256) s_bs[i] = bias[i];
-    for (int i = tid; i < CIN * A; i += 256) s_in[i] = planes[(size_t)b * CIN * A + i];
+    for (int bi = 0; bi < nb; ++bi)
+        for (int i = tid; i < CIN * A; i += 256) s_in0[bi * SI + i] = planes[(size_t)(b0 + bi) * CIN * A + i];
     __syncthreads();
-    h8* s_w = (h8*)(smem + C_pad * 4 + ((CIN * A + 15) & ~15) + 4 * 32 * STEM_SROW);   // [hi, lo][KS][4 tiles][64 lanes]
+    h8* s_w = (h8*)(smem + C_pad * 4 + bpb * SI + 4 * 32 * STEM_SROW);   // [hi, lo][KS][4 tiles][64 lanes]
+    const int PB = (P + 31) / 32;
     for (int c0 = 0; c0 < C_pad; c0 += 128) {
         // the weight pairs of a 128-channel slab, as the operand registers of lane `lane` for tile m: wave m builds tile m
         if (c0) __syncthreads();
@@ -280,7 +286,9 @@ az_stem_split_kernel(const uint8_t* __restrict__ planes, unsigned short* __restr
             s_w[((KS + ks) * 4 + wvi) * 64 + lane] = wl;
         }
         __syncthreads();
-        for (int pb = wvi; pb * 32 < P; pb += 4) {
+        for (int f = wvi; f < nb * PB; f += 4) {
+            const int bi = f / PB, pb = f - bi * PB, b = b0 + bi;
+            const uint8_t* s_in = s_in0 + bi * SI;
             const int p = pb * 32 + l31;
             const int y = p / W, x = p % W;
             const bool cell = p < P && y < N && x < N;
@@ -2186,6 +2194,7 @@ extern "C" int az_tower_configure(void) {
     SETA4(0); SETA4(1);
 #undef SETA4
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
+    SETA((az_stem_split_kernel<1, 3>), 80 * 1024); SETA((az_stem_split_kernel<1, 5>), 80 * 1024);
     SETA((az_heads_kernel<0, false>), 128 * 1024); SETA((az_heads_kernel<1, false>), 128 * 1024); SETA((az_heads_kernel<1, true>), 128 * 1024);
     SETA((az_tower_fused_kernel<0, 2>), 160 * 1024); SETA((az_tower_fused_kernel<1, 2>), 160 * 1024);
     SETA((az_tower_fused_kernel<0, 1>), 160 * 1024); SETA((az_tower_fused_kernel<1, 1>), 160 * 1024);
@@ -2210,9 +2219,11 @@ extern "C" void az_launch_stem(hipStream_t s, int prec, const uint8_t* planes, u
     if (c_in == 3 || c_in == 5) {
         static const bool stem32 = getenv("AZ_STEM_FP32") != nullptr;
         if (prec == 1 && !stem32 && C_pad == 128) {
-            const size_t sms = (size_t)C_pad * 4 + (size_t)((c_in * N * N + 15) & ~15) + 4 * 32 * STEM_SROW + (size_t)2 * ((c_in * 9 + 15) / 16) * 4 * 64 * 16;
-            if (c_in == 3) hipLaunchKernelGGL((az_stem_split_kernel<1, 3>), dim3(B), dim3(256), sms, s, planes, out, out32, out_lo, w, bias, N, C_pad, Gd);
-            else hipLaunchKernelGGL((az_stem_split_kernel<1, 5>), dim3(B), dim3(256), sms, s, planes, out, out32, out_lo, w, bias, N, C_pad, Gd);
+            const int bpb = B >= 2048 ? 4 : 1;                           // (a small batch keeps one board per block: more blocks than CUs first)
+            const size_t sms = (size_t)C_pad * 4 + (size_t)bpb * ((c_in * N * N + 15) & ~15) + 4 * 32 * STEM_SROW + (size_t)2 * ((c_in * 9 + 15) / 16) * 4 * 64 * 16;
+            const dim3 grid((B + bpb - 1) / bpb);
+            if (c_in == 3) hipLaunchKernelGGL((az_stem_split_kernel<1, 3>), grid, dim3(256), sms, s, planes, out, out32, out_lo, w, bias, N, C_pad, Gd, B, bpb);
+            else hipLaunchKernelGGL((az_stem_split_kernel<1, 5>), grid, dim3(256), sms, s, planes, out, out32, out_lo, w, bias, N, C_pad, Gd, B, bpb);
             return;
         }
         const size_t smm = (size_t)c_in * N * N + 16 + (size_t)C_pad * 4;
