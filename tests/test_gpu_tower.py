@@ -482,3 +482,19 @@ def test_fp16_pair_stem_and_heads_agree_with_the_fp32_mfma_forms(fixture, tmp_pa
     assert dp < 2e-6 and dv < 2e-6
     for o in outs:
         assert np.abs(o["pol"] - z["policy"]).max() < 1e-4 and np.abs(o["val"] - z["value"]).max() < 1e-4
+
+
+def test_stem_blocks_of_four_boards_equal_blocks_of_one(monkeypatch):
+    """The per-layer stem takes four boards per block from 2 048 boards on (ragged last block here) and one below:
+    the same boards give the same bits either way, three planes."""
+    monkeypatch.setenv("AZ_NO_FUSED", "1")
+    N, Cs, B = 9, synth.NETCONFIG2, 2050
+    eng = capi.Engine(N, 5, B, Cs=Cs, max_budget=1)
+    assert not eng.tower_is_fused()
+    eng.load_weights(synth.make_blob(N, 3, Cs, 12))
+    boards = synth.random_boards(B, N, seed=12)
+    pol, val = eng.tower_forward(boards)
+    for lo, hi in ((0, 1025), (1025, 2050)):
+        p, v = eng.tower_forward(boards[lo:hi])
+        assert np.array_equal(p, pol[lo:hi]) and np.array_equal(v, val[lo:hi])
+    assert eng.stats()["saturated"] == 0
