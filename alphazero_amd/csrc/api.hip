@@ -30,6 +30,12 @@ static std::mutex g_scratch_mu;
 // Pair launches (az_selfplay_run_pair) of different contexts on one GPU must not overlap: each wants every CU for its
 // tower workgroups and the one tree-wave slot beside each, and two half-resident pairs would wait for each other
 // until their time-outs.  One event per GPU, recorded behind every pair launch; the next one waits for it.
+// Streams of contexts that are gone, per GPU, for the contexts to come (first = a context's stream, second = the stream of
+// its pair's tree kernel, null when it had none).  A process that makes and drops contexts all day keeps its hardware
+// queues this way: every new queue is a round of taking all queues of the process off the GPU and putting them back,
+// and a queue's scratch memory is set up anew in the middle of its first kernel that needs some.
+static std::vector<std::pair<hipStream_t, hipStream_t>> g_stream_pool[AZ_MAX_DEVICES];
+static std::mutex g_stream_pool_mu;
 static hipEvent_t g_pair_done[AZ_MAX_DEVICES];          // per GPU: the end of the last pair launch of any context
 static const void* g_pair_last[AZ_MAX_DEVICES];         // ... and whose it was
 static std::mutex g_pair_mu[AZ_MAX_DEVICES];
@@ -247,7 +253,20 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
 static int ctx_build(az_ctx* c, const az_config* cfg) {
     const int N = cfg->N, A = N * N, G = cfg->G;
     c->A = A; c->W = N + 1; c->P = c->W * c->W; c->Gd = N + 2;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipStream_t pooled2 = nullptr;
+    if (cfg->device >= 0 && cfg->device < AZ_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        auto& pool = g_stream_pool[cfg->device];
+        // (a context that can run pairs takes two streams that ran side by side before, if there are such)
+        const bool two = cfg->eval_mode == AZ_EVAL_TOWER && (cfg->c_in == 0 || cfg->c_in == 3) && (cfg->c_out == 0 || cfg->c_out == 1) &&
+                         (cfg->value_dim == 0 || cfg->value_dim == 2);
+        for (size_t i = pool.size(); i-- > 0 && !c->stream;)
+            if ((pool[i].second != nullptr) == two) {
+                c->stream = pool[i].first; pooled2 = pool[i].second;
+                pool.erase(pool.begin() + (long)i);
+            }
+    }
+    if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     AzTreeDev& d = c->d;
     memset(&d, 0, sizeof d);
     d.G = G; d.N = N; d.A = A; d.K = cfg->K;
@@ -319,8 +338,9 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         std::vector<hipStream_t> failed;
         const bool no_probe = getenv("AZ_PAIR_NO_QUEUE_PROBE") != nullptr;          // (queue experiments)
         for (int attempt = 0; attempt < 8 && !c->stream2; ++attempt) {
-            hipStream_t s2 = nullptr;
-            HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            hipStream_t s2 = pooled2;
+            pooled2 = nullptr;
+            if (!s2) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
             bool ok = true;
             const int rc = no_probe ? (int)AZ_OK : queues_side_by_side(c->stream, s2, c->pair.start, &ok);
             if (rc != AZ_OK) { (void)hipStreamDestroy(s2); for (hipStream_t f : failed) (void)hipStreamDestroy(f); return rc; }
@@ -416,8 +436,13 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
         std::lock_guard<std::mutex> lk(g_pair_mu[c->cfg.device]);
         if (g_pair_last[c->cfg.device] == c) g_pair_last[c->cfg.device] = nullptr;
     }
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->cfg.device >= 0 && c->cfg.device < AZ_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        g_stream_pool[c->cfg.device].push_back({c->stream, c->stream2});
+    } else {
+        if (c->stream2) (void)hipStreamDestroy(c->stream2);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
     delete c;
     return AZ_OK;
 }
@@ -1048,24 +1073,30 @@ static const char* pair_unfit(const az_ctx* c) {
     return nullptr;
 }
 
-// Both kernels of the pair once with no rounds, on their streams, while nothing else runs: both spill a few registers,
-// and the first kernel with a private segment on a hardware queue makes the runtime set that queue's scratch memory up
-// in the middle of the dispatch.  Left to the first real launch, that happened with the tower workgroups already
-// spinning on the CUs, and once in a few process starts the launch then ran into its time-out.
+// Both kernels of the pair spill a few registers, and the first kernel with a private segment on a hardware queue makes
+// the runtime set that queue's scratch memory up in the middle of the dispatch.  Left to the first real launch, that
+// happened with the tower workgroups already spinning on the CUs, and about every other process start in which the
+// context's streams shared their hardware queues with streams of the caller's ran into the time-out there.  So a
+// kernel with the private segment of the tower kernel (80 bytes a lane) runs once on the context's stream and one with
+// the tree kernel's (128) on the other while the context is made, each with its kernel's grid.  (Not the pair
+// kernels themselves with no rounds: a profile's per-kernel averages would count those launches.  Not a larger
+// segment either: with 208 bytes on both streams the time-outs came back, one in three runs of the pair tests --
+// the more scratch the queues of a process hold, the sooner the runtime takes some back from a queue.)
+template <int WORDS>
+__global__ void __launch_bounds__(256) az_scratch_warm_kernel(unsigned* sink, int n) {
+    volatile unsigned buf[WORDS];
+    for (int i = 0; i < WORDS; ++i) buf[i] = threadIdx.x + (unsigned)i;
+    unsigned sum = 0u;
+    for (int i = 0; i < n; ++i) sum += buf[(threadIdx.x + (unsigned)i) % (unsigned)WORDS];
+    if (sum == 0xFFFFFFFFu) sink[0] = sum;
+}
 static int pair_warm_up(az_ctx* c) {
     if (c->tower_only || pair_unfit(c)) return AZ_OK;
-    AzPairDev pr = c->pair;
-    pr.base = 0; pr.rounds = 0; pr.timeout_ticks = 1000u; pr.flags = 0u; pr.started_want = 0u;
-    const int blocks = az_launch_tower_pair(c->stream, c->prec, (const uint8_t*)c->pair.planes_wt, c->stem_wbf, c->stem_b, c->conv_wf, c->conv_b,
-                                            c->head_pt, c->d.policy, c->d.value, c->cfg.G, c->cfg.N, c->Gd, 2 * c->num_res,
-                                            c->d_sat, &pr, c->n_cu);
-    if (blocks > 0) c->pair_started += (unsigned)blocks;
+    hipLaunchKernelGGL(az_scratch_warm_kernel<16>, dim3(c->n_cu), dim3(256), 0, c->stream, c->pair.start + 2, 3);
+    hipLaunchKernelGGL(az_scratch_warm_kernel<28>, dim3(c->n_cu), dim3(64), 0, c->stream2, c->pair.start + 2, 3);
     HIPCHK(hipStreamSynchronize(c->stream));
-    pr.started_want = c->pair_started;
-    az_launch_round_pair(c->stream2, &c->d, &pr, AZ_MODE_SELFPLAY, std::min(c->cfg.G, c->n_cu));
     HIPCHK(hipStreamSynchronize(c->stream2));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemset(c->pair.abort, 0, 32));
     return AZ_OK;
 }
 
