@@ -38,6 +38,16 @@ int main() {
     EXPECT(throws("x"));
     EXPECT(throws("1,,2"));
     EXPECT(throws("1,2,"));
+    // AZ_NET_CHANNELS: NetConfig 2 when unset, <channels>x<entries>, or a list
+    EXPECT(az::parse_channels(nullptr) == az::NetConfig::get(2).resblocks());
+    EXPECT(az::parse_channels("") == az::NetConfig::get(2).resblocks());
+    EXPECT((az::parse_channels("256x21") == V(21, 256)));
+    EXPECT((az::parse_channels("32,64,64") == V{32, 64, 64}));
+    for (const char* bad : {"256x1", "0x4", "x", "128x65", "64", "64,,64", "64,-1"}) {
+        bool threw = false;
+        try { az::parse_channels(bad); } catch (const az::Error&) { threw = true; }
+        EXPECT(threw);
+    }
 
     // workers: jobs run in order on their own thread, statuses and per-thread error texts come back
     {
