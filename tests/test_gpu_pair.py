@@ -29,6 +29,7 @@ CASES = [
     (15, 5, 16, 24, 400, [400]),             # 256-row tiles = one game per workgroup; 240 moves with re-roots
     (15, 5, 300, 40, 200, [50, 150]),        # more games than CUs: workgroups and tree waves take two games each
     (5, 4, 37, 16, 300, [100, 200]),         # seven boards per tile, ragged last tile, whole games and restarts
+    (15, 5, 1100, 16, 96, [40, 56]),         # four to five games per workgroup and tree wave
 ]
 
 
