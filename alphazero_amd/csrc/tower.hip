@@ -2101,6 +2101,20 @@ az_heads_kernel(const float* __restrict__ x /* fp32 residual stream */, const fl
         const int o = tid & 63, part = tid >> 6;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int a = part;
+        // sixteen rows in flight per thread: the loop is a chain of trips to L2 (the 100 KB of weights are read by every
+        // block), four at a time it took a sixth of a block's life
+        for (; a + 60 < A; a += 64) {
+            float w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = fc1t[(a + 4 * k) * 64 + o];
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                s0 += w[k] * s_u[a + 4 * k];
+                s1 += w[k + 1] * s_u[a + 4 * k + 4];
+                s2 += w[k + 2] * s_u[a + 4 * k + 8];
+                s3 += w[k + 3] * s_u[a + 4 * k + 12];
+            }
+        }
         for (; a + 12 < A; a += 16) {
             s0 += fc1t[a * 64 + o] * s_u[a];
             s1 += fc1t[(a + 4) * 64 + o] * s_u[a + 4];
