@@ -26,16 +26,19 @@ def main():
     ap.add_argument("--reuse", action="store_true",
                     help="the reference's loop in full: the tree is carried from move to move (__make_root + find, mcts.hpp:385-421) and "
                          "every game starts with a warm-up search (generate.cpp:77)")
+    ap.add_argument("--leaves", type=int, default=1,
+                    help="descents per game and round under virtual loss (MCTS(nthreads, ...), mcts.hpp:54-72): a round evaluates "
+                         "games x leaves positions")
     a = ap.parse_args()
     from alphazero_amd import capi, synth
     dev = capi.Blokus(a.games, seed=3)
-    dev.search_config(max_budget=a.budget, reuse=a.reuse)
+    dev.search_config(max_budget=a.budget, reuse=a.reuse, leaves=a.leaves)
     dev.playout(a.pieces)
     dev.sync()
     tower = None
     if a.tower:
         Cs = synth.NETCONFIG2
-        tower = capi.Engine(20, 5, a.games, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+        tower = capi.Engine(20, 5, a.games * a.leaves, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
         tower.load_weights(synth.make_blob(20, 5, Cs, 0, c_out=91, value_dim=4))
     run = (lambda b: dev.search_tower(tower, b)) if a.tower else dev.search
     run(8)                                          # warm-up
@@ -69,8 +72,8 @@ def main():
                       "config": {"workload": "blokus 20x20 4-player, %d concurrent games x %d sims per search, %s" % (
                                      a.games, a.budget, "NetConfig-2 tower (stem + 9 ResBlocks x 128 ch, 5 planes in, 91 policy channels, 4 values), "
                                      "fp16 operands, random-init weights" if a.tower else "integer-hash evaluator (env + tree kernels only)"),
-                                 "pieces_on_board": a.pieces, "mean_legal_actions_at_root": float(count.mean())},
-                      "ms_per_round": el / (a.searches * (a.budget + 3)) * 1e3, "searches": a.searches, "seconds": el, "tree": st,
+                                 "pieces_on_board": a.pieces, "leaves_per_round": a.leaves, "mean_legal_actions_at_root": float(count.mean())},
+                      "ms_per_round": el / (a.searches * (-(-a.budget // a.leaves) + 3)) * 1e3, "searches": a.searches, "seconds": el, "tree": st,
                       **({"selfplay": selfplay} if selfplay else {})}))
 
 
