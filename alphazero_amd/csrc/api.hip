@@ -111,6 +111,7 @@ struct az_ctx {
     // the persistent pair (az_selfplay_run_pair): the tree kernel's own stream, the events that order it against the
     // context's stream, the hand-over words, what the launches so far have published
     hipStream_t stream2 = nullptr;
+    hipStream_t pooled2 = nullptr;                      // (while the context is built: a second stream taken over from a context before it)
     hipEvent_t pair_join = nullptr;                     // the tree kernel of the last pair launch has ended
     unsigned pair_started = 0;                          // tower workgroups launched by the pair launches so far
     int pair_queue_attempts = 0;                        // streams tried until one ran side by side with the context's (0: none did)
@@ -253,7 +254,7 @@ extern "C" int az_ctx_create(az_ctx** out, const az_config* cfg) {
 static int ctx_build(az_ctx* c, const az_config* cfg) {
     const int N = cfg->N, A = N * N, G = cfg->G;
     c->A = A; c->W = N + 1; c->P = c->W * c->W; c->Gd = N + 2;
-    hipStream_t pooled2 = nullptr;
+    hipStream_t& pooled2 = c->pooled2;                      // (in the context: a build that fails early still hands it back)
     if (cfg->device >= 0 && cfg->device < AZ_MAX_DEVICES) {
         std::lock_guard<std::mutex> lk(g_stream_pool_mu);
         auto& pool = g_stream_pool[cfg->device];
@@ -340,7 +341,10 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
         for (int attempt = 0; attempt < 8 && !c->stream2; ++attempt) {
             hipStream_t s2 = pooled2;
             pooled2 = nullptr;
-            if (!s2) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            if (!s2 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) {
+                for (hipStream_t f : failed) (void)hipStreamDestroy(f);
+                return fail(AZ_E_HIP, "no stream for the pair's tree kernel: %s", hipGetErrorString(hipGetLastError()));
+            }
             bool ok = true;
             const int rc = no_probe ? (int)AZ_OK : queues_side_by_side(c->stream, s2, c->pair.start, &ok);
             if (rc != AZ_OK) { (void)hipStreamDestroy(s2); for (hipStream_t f : failed) (void)hipStreamDestroy(f); return rc; }
@@ -438,7 +442,7 @@ extern "C" int az_ctx_destroy(az_ctx* c) {
     }
     if (c->stream && c->cfg.device >= 0 && c->cfg.device < AZ_MAX_DEVICES) {
         std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-        g_stream_pool[c->cfg.device].push_back({c->stream, c->stream2});
+        g_stream_pool[c->cfg.device].push_back({c->stream, c->stream2 ? c->stream2 : c->pooled2});
     } else {
         if (c->stream2) (void)hipStreamDestroy(c->stream2);
         if (c->stream) (void)hipStreamDestroy(c->stream);
