@@ -41,7 +41,7 @@ def cpu_baseline(seconds, N, K, budget, nthreads):
         with tempfile.TemporaryDirectory() as d:
             try:
                 out = subprocess.run([ref, "bench", str(N), str(K), str(nthreads), str(budget), str(seconds), d],
-                                     env=env, capture_output=True, text=True, timeout=seconds * 6 + 120).stdout
+                                     env=env, capture_output=True, text=True, timeout=seconds * 2 + 60).stdout
                 line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
                 r = json.loads(line)
                 return {"value": r["sims_per_s"], "unit": "sims/s", "cores": int(r["torch_threads"]), "kind": "reference",
