@@ -84,7 +84,7 @@ struct az_ctx {
     bool split = false;                                   // AZ_PREC_FP16X3: operands as hi + lo pairs, convolutions over 3x the channels
     bool tower_only = false;                              // a tower whose shape no m,n,k search can use: no tree state allocated
     unsigned short *catX = nullptr, *catH = nullptr;      // split: [rows][3 C_pad] = [hi | lo | hi] of the stream / the hidden activation
-    float* actS = nullptr;                                // split: fp32 image of a block's hidden activation
+    float* actS = nullptr;                                // split, AZ_X3_SEPARATE_SPLIT only: fp32 image of a block's hidden activation
     unsigned short* conv_w3 = nullptr;                    // split: [W_hi | W_hi | W_lo] images, 3x conv_w
     int* d_range = nullptr;                               // [4] range tally of the fold's dry run (weights.hip)
     unsigned long long* d_sat = nullptr;                  // [1] az_stats.saturated
@@ -408,7 +408,7 @@ static int ctx_build(az_ctx* c, const az_config* cfg) {
                 if (c->conv_kind != 0) return fail(AZ_E_ARG, "AZ_PREC_FP16X3 runs on the default per-layer kernel only (unset AZ_T256_32 / AZ_CONV_T128)");
                 AZCHK(dalloc(c, &c->catX, c->act_rows * c->C_pad * 3));
                 AZCHK(dalloc(c, &c->catH, c->act_rows * c->C_pad * 3));
-                AZCHK(dalloc(c, &c->actS, c->act_rows * c->C_pad));
+                if (getenv("AZ_X3_SEPARATE_SPLIT")) AZCHK(dalloc(c, &c->actS, c->act_rows * c->C_pad));
                 AZCHK(dalloc(c, &c->conv_w3, c->conv_layer_elems * 3 * 2 * c->num_res));
             }
             AZCHK(dalloc(c, &c->head_p, (size_t)(c->c_out + 1) * c->C_pad + c->c_out + 1 + 64 * (size_t)A + 64 + 64 * (size_t)c->vd + c->vd));
@@ -589,25 +589,31 @@ static int tower_launch(az_ctx* c, const uint8_t* planes_dev, int B, float* pol_
     if (c->split) {
         // AZ_PREC_FP16X3.  Every operand is a pair hi + lo of fp16 values; conv(W, x) = W_hi x_hi + W_hi x_lo + W_lo x_hi
         // as ONE reduction over three times the channels (activation rows [hi | lo | hi], weight image [W_hi | W_hi |
-        // W_lo], see az_cat3_kernel) on the per-layer path's own kernel.  The layer outputs are taken in fp32 (the
-        // residual form writes its sum back to the fp32 image it read: the residual stream for a block's second
-        // convolution, a zeroed image for its first) and re-split; the kernels' 16-bit outputs go unused.
+        // W_lo], see az_cat3_kernel) on the per-layer path's own kernel, whose epilogue splits the fp32 layer output
+        // into the next convolution's [hi | lo | hi] rows (az_launch_conv3x3_cat); the residual stream stays one fp32
+        // image, updated in place.  AZ_X3_SEPARATE_SPLIT=1 keeps the first form for the A/B: fp32 layer outputs through
+        // the residual form (on a zeroed image for a block's first convolution), split by az_cat3_kernel -- the same
+        // arithmetic, bit for bit, with a memset and two more passes over HBM per block.
         const size_t M_pad = ((size_t)M + 255) / 256 * 256;
         const size_t body = (size_t)Gd * Cp;                                      // the rows between the guards
+        const bool separate = c->actS != nullptr;                                   // (AZ_X3_SEPARATE_SPLIT when the context was made)
         az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
         for (int i = 0; i < c->num_res; ++i) {
             const unsigned short* w1 = c->conv_w3 + (size_t)(2 * i) * 3 * c->conv_layer_elems;
             const unsigned short* w2 = w1 + 3 * c->conv_layer_elems;
             const float* b1 = c->conv_b + (size_t)(2 * i) * Cp;
-            HIPCHK(hipMemsetAsync(c->actS + body, 0, M_pad * Cp * 4, c->stream));
+            if (separate) HIPCHK(hipMemsetAsync(c->actS + body, 0, M_pad * Cp * 4, c->stream));
             bool on = prof_begin(c, 0, sampled, c->stream);
-            az_launch_conv3x3(c->stream, c->prec, 0, c->catX, actH, c->actS, nullptr, w1, b1, Cp, M, N, Gd, 1, 3 * Cp);
+            if (separate) az_launch_conv3x3(c->stream, c->prec, 0, c->catX, actH, c->actS, nullptr, w1, b1, Cp, M, N, Gd, 1, 3 * Cp);
+            else az_launch_conv3x3_cat(c->stream, c->prec, c->catX, c->catH, nullptr, w1, b1, Cp, M, N, Gd, 3 * Cp);
             prof_end(c, on, c->stream);
-            az_launch_cat3(c->stream, c->prec, c->actS + body, c->catH + 3 * body, M_pad, Cp);
+            if (separate) az_launch_cat3(c->stream, c->prec, c->actS + body, c->catH + 3 * body, M_pad, Cp);
             on = prof_begin(c, 0, sampled, c->stream);
-            az_launch_conv3x3(c->stream, c->prec, 0, c->catH, actX, actR, nullptr, w2, b1 + Cp, Cp, M, N, Gd, 1, 3 * Cp);
+            // (the last block's output feeds the heads only: they read the fp32 stream)
+            if (separate || i + 1 == c->num_res) az_launch_conv3x3(c->stream, c->prec, 0, c->catH, actX, actR, nullptr, w2, b1 + Cp, Cp, M, N, Gd, 1, 3 * Cp);
+            else az_launch_conv3x3_cat(c->stream, c->prec, c->catH, c->catX, actR, w2, b1 + Cp, Cp, M, N, Gd, 3 * Cp);
             prof_end(c, on, c->stream);
-            az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
+            if (separate && i + 1 < c->num_res) az_launch_cat3(c->stream, c->prec, actR + body, c->catX + 3 * body, M_pad, Cp);
         }
         az_launch_heads(c->stream, c->prec, actR, c->head_p, pol_dev, val_dev, B, N, Cp, Gd, c->c_out, c->vd, c->d_sat, mask);
         HIPCHK(hipGetLastError());

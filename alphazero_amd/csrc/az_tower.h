@@ -18,6 +18,11 @@ int  az_conv_kind(void);                                          // per-layer c
 void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsigned short* in, unsigned short* out,
                        float* resid, unsigned short* lo, const unsigned short* wpk, const float* bias,
                        int C_pad, int M, int N, int Gd, int relu, int Cin /* channels of `in`, 0 = C_pad (kind 0 only) */);
+// kind 0 with the output written as the compensated mode's [hi | lo | hi] image (rows of 3 C_pad values); resid: the
+// fp32 residual stream, updated in place, or null for a block's first convolution
+void az_launch_conv3x3_cat(hipStream_t s, int prec, const unsigned short* in, unsigned short* cat_out,
+                           float* resid, const unsigned short* wpk, const float* bias,
+                           int C_pad, int M, int N, int Gd, int Cin);
 void az_launch_tower_fused(hipStream_t s, int prec, const uint8_t* planes, const unsigned short* stem_w,
                            const float* stem_b, const unsigned short* wpk, const float* bias,
                            const float* hp, float* policy, float* value, int B, int N, int Gd, int n_layers,

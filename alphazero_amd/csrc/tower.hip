@@ -867,13 +867,15 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const u32x4& a, const u32x4& 
 // residual stream x is kept: 1 = one fp32 image (resid), updated in place; 2 = a pair of 16-bit images hi + lo, hi =
 // the 16-bit image the next convolution reads anyway (`out`, read here before it is overwritten), lo = the rounding
 // remainder x - hi, scaled (`lo`, updated in place; AZ_LO_SCALE): 22 significant bits in fp16, and 8 bytes per element through HBM
-// instead of 10; 3 = hi + lo in, fp32 out (the last block: the heads read resid).  RELU: network.hpp:33,36.
+// instead of 10; 3 = hi + lo in, fp32 out (the last block: the heads read resid).  4 and 5 (the compensated mode): 0 and 1
+// with `out` an image of 3 C_pad values per row that takes the output as [hi | lo | hi] (az_cat3_kernel's split, here
+// in the epilogue: the next convolution's input without another pass over HBM).  RELU: network.hpp:33,36.
 // Template parameters so that the epilogue is straight-line code (as run-time flags they cost three branches and
 // both conversions per four values).
 template <int PR, int RM, bool RELU>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* out,
-                       float* resid /* RM 1: the fp32 stream, in and out; RM 3: out */, unsigned short* lo /* RM 2, 3 */,
+                       float* resid /* RM 1, 5: the fp32 stream, in and out; RM 3: out */, unsigned short* lo /* RM 2, 3 */,
                        const unsigned short* __restrict__ wpk,
                        const float* __restrict__ bias, int C_pad, int M, int n_tiles, int N, int Gd, int xcd_tiles,
                        int Cin /* channels (and row pitch) of `in` = the reduction's extent; C_pad except in the compensated mode */) {
@@ -946,10 +948,15 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* o
     // -- no address registers per access.
     const size_t tile0 = (size_t)(Gd + m0) * C_pad + nb * 128;
     const unsigned lane0 = (unsigned)((64 * wv + 4 * gc) * C_pad + 4 * lrc);                 // in elements
-    constexpr bool RESID = RM == 1, HILO = RM >= 2;
+    constexpr bool RESID = RM == 1 || RM == 5, HILO = RM == 2 || RM == 3, CAT = RM >= 4, R32 = RM == 1 || RM == 3 || RM == 5;
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((RM == 1 || RM == 3) ? resid + tile0 : (float*)nullptr), 0, (RM == 1 || RM == 3) ? T4_M * C_pad * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(out + tile0), 0, T4_M * C_pad * 2, 0x00020000);
+        (void*)(R32 ? resid + tile0 : (float*)nullptr), 0, R32 ? T4_M * C_pad * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(CAT ? (unsigned short*)nullptr : out + tile0), 0, CAT ? 0 : T4_M * C_pad * 2, 0x00020000);
+    // CAT: `out` is an image with rows of 3 C_pad values, [hi | lo | hi] of the layer's output (see az_cat3_kernel)
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(CAT ? out + (size_t)(Gd + m0) * (3 * C_pad) + nb * 128 : (unsigned short*)nullptr), 0, CAT ? T4_M * 3 * C_pad * 2 : 0, 0x00020000);
+    const unsigned lane0c = (unsigned)((64 * wv + 4 * gc) * (3 * C_pad) + 4 * lrc);
     const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(HILO ? lo + tile0 : (unsigned short*)nullptr), 0, HILO ? T4_M * C_pad * 2 : 0, 0x00020000);
 #pragma unroll
@@ -1161,7 +1168,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* o
                 for (int q = 0; q < 2; ++q) {
                     const int so = (16 * b + r) * C_pad + 64 * q;                            // scalar: row and channel half
                     float v0 = acc[4 * q][b][r], v1 = acc[4 * q + 1][b][r], v2 = acc[4 * q + 2][b][r], v3 = acc[4 * q + 3][b][r];
-                    if constexpr (RM != 0) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
+                    if constexpr (RESID || HILO) { v0 += rv[q][bb][r].x; v1 += rv[q][bb][r].y; v2 += rv[q][bb][r].z; v3 += rv[q][bb][r].w; }
                     uint2 o;
                     if constexpr (RELU) {
                         v0 = relu_cap(v0, cap); v1 = relu_cap(v1, cap); v2 = relu_cap(v2, cap); v3 = relu_cap(v3, cap);
@@ -1171,7 +1178,7 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* o
                         o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
                         o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                     }
-                    if constexpr (RM == 1 || RM == 3)
+                    if constexpr (R32)
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)},
                                                                rrs, lane0 * 4, so * 4, 0);
                     if constexpr (RM == 2) {                                 // what the 16-bit copy drops, as a second 16-bit value
@@ -1181,7 +1188,20 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* o
                                                             (v3 - Prec<PR>::from16((unsigned short)(o.y >> 16))) * AZ_LO_SCALE);
                         __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, lrs, lane0 * 2, so * 2, 0);
                     }
-                    if constexpr (RM != 3)                                   // (the last block's output feeds the heads only)
+                    if constexpr (CAT) {                                     // hi, the remainder as it is (22 bits together), hi again
+                        // The remainders are computed in the registers the four-dword store above has just been given
+                        // (v_pk_add_f32 right behind buffer_store_dwordx4 with a scalar offset): without wait states in
+                        // between, the fp32 stream on the MI355X came out different from run to run -- a hazard the
+                        // compiler's table does not list for stores with a scalar offset.
+                        if constexpr (R32) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 3"); __builtin_amdgcn_sched_barrier(0); }
+                        const unsigned l0 = Prec<PR>::pack2(v0 - Prec<PR>::from16((unsigned short)o.x), v1 - Prec<PR>::from16((unsigned short)(o.x >> 16)));
+                        const unsigned l1 = Prec<PR>::pack2(v2 - Prec<PR>::from16((unsigned short)o.y), v3 - Prec<PR>::from16((unsigned short)(o.y >> 16)));
+                        const int soc = (16 * b + r) * (3 * C_pad) + 64 * q;
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, crs, lane0c * 2, soc * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, crs, lane0c * 2, (soc + C_pad) * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, crs, lane0c * 2, (soc + 2 * C_pad) * 2, 0);
+                    }
+                    if constexpr (RM != 3 && !CAT)                           // (the last block's output feeds the heads only)
                         __builtin_amdgcn_raw_buffer_store_b64((u32x2){o.x, o.y}, ors, lane0 * 2, so * 2, 0);
                 }
             }
@@ -2204,7 +2224,8 @@ extern "C" int az_tower_configure(void) {
     SETA(az_conv3x3_t128_kernel<0>, 80 * 1024 + 512); SETA(az_conv3x3_t128_kernel<1>, 80 * 1024 + 512);
     SETA(az_conv3x3_t256_kernel<0>, 80 * 1024); SETA(az_conv3x3_t256_kernel<1>, 80 * 1024);
 #define SETA4(pr) SETA((az_conv3x3_t256s_kernel<pr, 0, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, 1, true>), 80 * 1024); \
-                  SETA((az_conv3x3_t256s_kernel<pr, 2, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, 3, true>), 80 * 1024)
+                  SETA((az_conv3x3_t256s_kernel<pr, 2, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, 3, true>), 80 * 1024); \
+                  SETA((az_conv3x3_t256s_kernel<pr, 4, true>), 80 * 1024); SETA((az_conv3x3_t256s_kernel<pr, 5, true>), 80 * 1024)
     SETA4(0); SETA4(1);
 #undef SETA4
     SETA(az_stem_kernel<0>, 64 * 1024); SETA(az_stem_kernel<1>, 64 * 1024);
@@ -2291,6 +2312,24 @@ extern "C" void az_launch_conv3x3(hipStream_t s, int prec, int kind, const unsig
     const size_t sm = (size_t)(T2_M + 2 * Gd) * A_STRIDE + 2 * W2_BYTES;
     BY_PREC(az_conv3x3_t128_kernel, dim3(tiles, C_pad / 128), dim3(256), sm, s,
             in, out, resid, wpk, bias, C_pad, M, N, Gd, relu);
+}
+
+// The same convolution with its output written as the [hi | lo | hi] image the compensated mode's next convolution
+// reads (rows of 3 C_pad values; az_cat3_kernel's arithmetic in the epilogue).  resid: the fp32 residual stream,
+// updated in place (a block's second convolution), or null (its first).
+extern "C" void az_launch_conv3x3_cat(hipStream_t s, int prec, const unsigned short* in, unsigned short* cat_out,
+                                      float* resid, const unsigned short* wpk, const float* bias,
+                                      int C_pad, int M, int N, int Gd, int Cin) {
+    const int tiles = (M + T4_M - 1) / T4_M;
+    size_t sm = 2 * (size_t)W2_BYTES + (size_t)t4_slab_rows(Gd) * 128;
+    if (sm < (size_t)T4_M * 256) sm = (size_t)T4_M * 256;
+    const int xcd_tiles = (tiles + 7) / 8;
+    const dim3 grid(8 * xcd_tiles * (C_pad / 128));
+#define T4C_GO(pr, rm) hipLaunchKernelGGL((az_conv3x3_t256s_kernel<pr, rm, true>), grid, dim3(256), sm, s, \
+                                          in, cat_out, resid, (unsigned short*)nullptr, wpk, bias, C_pad, M, tiles, N, Gd, xcd_tiles, Cin)
+    if (prec == 1) { if (resid) T4C_GO(1, 5); else T4C_GO(1, 4); }
+    else { if (resid) T4C_GO(0, 5); else T4C_GO(0, 4); }
+#undef T4C_GO
 }
 
 // Tile height of the fused kernel for a batch

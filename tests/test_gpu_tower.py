@@ -484,6 +484,28 @@ def test_fp16_pair_stem_and_heads_agree_with_the_fp32_mfma_forms(fixture, tmp_pa
         assert np.abs(o["pol"] - z["policy"]).max() < 1e-4 and np.abs(o["val"] - z["value"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("fixture", ["tower_n20_in5_out91.npz", "tower_n15_cfg2_spread_sharp.npz", "tower_n15_c256x21_spread.npz"])
+def test_compensated_mode_split_in_the_epilogue_equals_the_separate_split(fixture, tmp_path, monkeypatch):
+    """AZ_PREC_FP16X3: the convolution that writes its output as the next one's [hi | lo | hi] rows against the first
+    form (fp32 layer outputs, split by a kernel of its own; AZ_X3_SEPARATE_SPLIT, read once per process: one child
+    process each).  The same arithmetic: the same bits, 128 and 256 channels, 15x15 and 20x20."""
+    import subprocess
+    import sys
+    monkeypatch.setenv("AZ_NO_FUSED", "1")
+    root = os.path.dirname(GOLDEN[:-len("/golden")])
+    path = os.path.join(GOLDEN, fixture)
+    outs = []
+    for tag, env in (("epilogue", {}), ("separate", {"AZ_X3_SEPARATE_SPLIT": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _FORMS % (root, path, out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["pol"], outs[1]["pol"]) and np.array_equal(outs[0]["val"], outs[1]["val"])
+    z = np.load(path)
+    assert np.abs(outs[0]["pol"] - z["policy"]).max() < 1e-4 and np.abs(outs[0]["val"] - z["value"]).max() < 1e-4
+
+
 def test_stem_blocks_of_four_boards_equal_blocks_of_one(monkeypatch):
     """The per-layer stem takes four boards per block from 2 048 boards on (ragged last block here) and one below:
     the same boards give the same bits either way, three planes."""
