@@ -1115,11 +1115,11 @@ static int pair_check(az_ctx* c) {
     if (!c->pair_launches) return AZ_OK;
     unsigned ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpy(ab, c->pair.abort, 32, hipMemcpyDeviceToHost));
-    if (ab[0]) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out (the %s of game %u wanted word %u and saw %u; waits saw the clock step %u times: "
+    if (ab[0]) return fail(AZ_E_STATE, "a hand-over wait of the persistent tower/tree pair ran out (the %s, index %u, wanted word %u and saw %u; waits saw the clock step %u times: "
                                         "that often the waves were taken off the GPU and put back): "
                                         "the two kernels were not resident together (another process on this GPU, or a profiler that "
                                         "serialises launches); the games of this context are no longer in step -- run such set-ups with "
-                                        "az_selfplay_run", ab[1] == 0xC0000000u ? "gate in front of the tree kernel, waiting for the tower workgroups to begin; not a wait" : (ab[1] >> 31) ? "tree wave" : "tower workgroup",
+                                        "az_selfplay_run", ab[1] == 0xC0000000u ? "gate in front of the tree kernel, which waits for the tower workgroups to begin" : (ab[1] >> 31) ? "tree wave of the game" : "tower workgroup",
                                         ab[1] & 0x3FFFFFFFu, ab[2], ab[3], ab[4]);
     return AZ_OK;
 }
