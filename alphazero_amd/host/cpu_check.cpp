@@ -49,6 +49,15 @@ int main() {
         EXPECT(threw);
     }
 
+    // AZ_PRECISION
+    EXPECT(az::parse_precision(nullptr) == AZ_PREC_FP16 && az::parse_precision("") == AZ_PREC_FP16 && az::parse_precision("fp16") == AZ_PREC_FP16);
+    EXPECT(az::parse_precision("bf16") == AZ_PREC_BF16 && az::parse_precision("fp16x3") == AZ_PREC_FP16X3);
+    for (const char* bad : {"fp32", "FP16", "x3", "fp16x"}) {
+        bool threw = false;
+        try { az::parse_precision(bad); } catch (const az::Error&) { threw = true; }
+        EXPECT(threw);
+    }
+
     // workers: jobs run in order on their own thread, statuses and per-thread error texts come back
     {
         std::vector<az_worker::Worker*> ws;

@@ -39,7 +39,7 @@ int main(int argc, char const* argv[]) {
 
     const std::vector<int> devices = az::parse_gpus(getenv("AZ_GPUS"), dev ? atoi(dev) : 0, az_device_count());
     az::SelfPlay<Env> agent(games, iter_budget, 3, 3, devices[0], std::random_device{}(), 0, 0, devices,
-                            az::parse_channels(getenv("AZ_NET_CHANNELS")));
+                            az::parse_channels(getenv("AZ_NET_CHANNELS")), az::parse_precision(getenv("AZ_PRECISION")));
     std::cout << "GPUs: " << devices.size() << " | games per GPU: " << games << std::endl;
     az::ReplayBuffer<Env> buffer(GEN, "*", port ? port : "5555");
     agent.load();
@@ -53,7 +53,7 @@ int main(int argc, char const* argv[]) {
         setenv("AZ_CHAIN", "6", 0);
         try {
             agent.begin();
-            agent.run(8);
+            agent.run_pair(8);
             (void)agent.stats();
             pair = true;
         } catch (const az::Error& e) {

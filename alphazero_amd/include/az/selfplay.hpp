@@ -73,6 +73,18 @@ inline std::vector<int> parse_channels(const char* spec) {
     return c;
 }
 
+// "AZ_PRECISION": the operand format of the tower's kernels (az_config.precision): "fp16" (the default when unset),
+// "bf16", or "fp16x3", the compensated mode that holds the reference's fp32 outputs to 1e-4 on every tower at about
+// a quarter of the rate.
+inline int parse_precision(const char* spec) {
+    if (!spec || !*spec) return AZ_PREC_FP16;
+    const std::string s(spec);
+    if (s == "fp16") return AZ_PREC_FP16;
+    if (s == "bf16") return AZ_PREC_BF16;
+    if (s == "fp16x3") return AZ_PREC_FP16X3;
+    throw Error("AZ_PRECISION: expected fp16, bf16 or fp16x3");
+}
+
 template <class Env>
 class SelfPlay {
 public:
@@ -82,8 +94,10 @@ public:
     // tower / tree pair per call on every context that can (az_selfplay_run_pair), AZ_CHAIN=k lets simulations
     // that end in a stored terminal leaf ride along (az_selfplay_chain).
     // `channels`: the tower (NetConfig::resblocks() form); empty = NetConfig::get(2), the reference's (generate.cpp:58).
+    // `precision`: AZ_PREC_* (see parse_precision).
     SelfPlay(int games, int iter_budget, float vl = 3, float c_puct = 3, int device = 0, uint64_t seed = 0,
-             int slot_base = 0, int contexts = 0, std::vector<int> devices = {}, std::vector<int> channels = {})
+             int slot_base = 0, int contexts = 0, std::vector<int> devices = {}, std::vector<int> channels = {},
+             int precision = AZ_PREC_FP16)
         : G(games), budget(iter_budget), Cs(channels.empty() ? NetConfig::get(2).resblocks() : channels) {
         if (devices.empty()) devices = {device};
         if (contexts <= 0) { const char* e = getenv("AZ_CONTEXTS"); contexts = e ? atoi(e) : 1; }
@@ -94,7 +108,7 @@ public:
         for (size_t k = 0; k < Cs.size(); ++k) cfg.Cs[k] = Cs[k];
         cfg.vl = vl; cfg.c_puct = c_puct; cfg.max_budget = iter_budget;
         cfg.eval_mode = AZ_EVAL_TOWER; cfg.noise_mode = AZ_NOISE_DEVICE;
-        cfg.seed = seed; cfg.game_slot_base = slot_base;
+        cfg.seed = seed; cfg.game_slot_base = slot_base; cfg.precision = precision;
         check(az_group_create(&grp, &cfg, devices.data(), (int)devices.size(), contexts));
         n_gpus = (int)devices.size();
     }
@@ -155,6 +169,10 @@ public:
     az_stats stats() { az_stats t{}; check(az_group_get_stats(grp, &t)); return t; }
     az_ctx* context(int i = 0) const { return az_group_context(grp, i); }
     int contexts() const { return az_group_contexts(grp); }
+    // `rounds` rounds of every context as one launch of the persistent tower / tree pair, context after context: throws
+    // with the library's reason where a context cannot run that form (run() with AZ_PAIR=1 takes lockstep rounds there
+    // without saying so).  For a trial at start-up; begin() afterwards puts the games back in step.
+    void run_pair(int rounds) { for (int i = 0; i < contexts(); ++i) check(az_selfplay_run_pair(context(i), rounds)); }
     int gpus() const { return n_gpus; }
     const std::string& model() const { return model_path; }
     const int G, budget;

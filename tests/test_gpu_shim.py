@@ -65,11 +65,12 @@ def test_checkpoint_swap_mid_run_goes_through_the_group_load_and_the_device_fold
         assert "cannot be read" in out.stdout and "Resuming with network model_1.pt" in out.stdout
 
 
-@pytest.mark.parametrize("channels,fail_after", [(None, None), ("32x4", None), (None, 2)])
+@pytest.mark.parametrize("channels,fail_after,precision", [(None, None, None), ("32x4", None, None), (None, 2, None), (None, None, "fp16x3")])
 @pytest.mark.skipif(find_libzmq() is None, reason="no libzmq for the PULL side")
-def test_generate_executable_streams_rows_to_a_pull_socket(channels, fail_after):
+def test_generate_executable_streams_rows_to_a_pull_socket(channels, fail_after, precision):
     """channels: AZ_NET_CHANNELS, a tower other than the compiled-in NetConfig 2 (a fresh checkpoint of that shape is
-    written and read back like any other).  fail_after: the persistent pair loses its tree kernel at that launch
+    written and read back like any other).  precision: AZ_PRECISION (the compensated mode runs lockstep rounds on the
+    per-layer kernels: the start-up trial of the pair says so).  fail_after: the persistent pair loses its tree kernel at that launch
     (AZ_PAIR_FAIL_AFTER, a 50 ms time-out): the producer says so, restarts its games as lockstep rounds and keeps
     streaming."""
     exe = os.path.join(HOST, "generate")
@@ -90,6 +91,8 @@ def test_generate_executable_streams_rows_to_a_pull_socket(channels, fail_after)
         env = dict(os.environ, AZ_GAMES="32", AZ_PORT=str(port), AZ_SECONDS="60")
         if channels:
             env["AZ_NET_CHANNELS"] = channels
+        if precision:
+            env["AZ_PRECISION"] = precision
         if fail_after is not None:
             env.update(AZ_PAIR_FAIL_AFTER=str(fail_after), AZ_PAIR_TIMEOUT_MS="50")
         log = open(os.path.join(d, "generate.out"), "w")
@@ -134,5 +137,7 @@ def test_generate_executable_streams_rows_to_a_pull_socket(channels, fail_after)
         out = open(os.path.join(d, "generate.out")).read()
         if fail_after is not None:
             assert "games restarted as lockstep rounds" in out, out[-2000:]
+        elif precision == "fp16x3":
+            assert "does not run here" in out and "using lockstep rounds" in out, out[-2000:]
         else:
             assert "lockstep rounds" not in out, out[-2000:]
