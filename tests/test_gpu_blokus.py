@@ -294,10 +294,12 @@ def test_search_at_config_size_2048_games_400_sims():
         assert np.array_equal(got[k], want[k]), k
 
 
-def test_search_with_the_tower_as_evaluator():
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3"])
+def test_search_with_the_tower_as_evaluator(precision):
     """The Blokus search fed by the HIP tower (20x20, 5 planes in, 91 policy channels and 4 values out) instead
     of the hash evaluator, device to device: the root's priors are the tower's softmax at the legal actions
-    (bit for bit: same kernels on the same planes), every simulation is accounted for, values stay in range."""
+    (bit for bit: same kernels on the same planes), every simulation is accounted for, values stay in range.
+    Either operand format of the tower: the default and the compensated one."""
     from alphazero_amd import synth
     G, budget = 16, 24
     Cs = synth.NETCONFIG2
@@ -305,7 +307,8 @@ def test_search_with_the_tower_as_evaluator():
     dev.search_config(max_budget=budget)
     dev.playout(6)
     dev.sync()
-    tower = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+    tower = capi.Engine(20, 5, G, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1,
+                        precision={"fp16": capi.AZ_PREC_FP16, "fp16x3": capi.AZ_PREC_FP16X3}[precision])
     tower.load_weights(synth.make_blob(20, 5, Cs, 31, phead_gain=4.0, fc2_gain=2.0, c_out=91, value_dim=4))
     with pytest.raises(capi.AzError, match="c_in 5"):
         dev.search_tower(capi.Engine(20, 5, G, Cs=Cs, max_budget=1), budget)       # an m,n,k-shaped tower
