@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=1,
                     help="descents per game and round under virtual loss (MCTS(nthreads, ...), mcts.hpp:54-72): a round evaluates "
                          "games x leaves positions")
+    ap.add_argument("--precision", choices=["fp16", "bf16", "fp16x3"], default="fp16", help="operand format of the tower (--tower)")
     a = ap.parse_args()
     from alphazero_amd import capi, synth
     dev = capi.Blokus(a.games, seed=3)
@@ -38,7 +39,8 @@ def main():
     tower = None
     if a.tower:
         Cs = synth.NETCONFIG2
-        tower = capi.Engine(20, 5, a.games * a.leaves, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1)
+        tower = capi.Engine(20, 5, a.games * a.leaves, Cs=Cs, c_in=5, c_out=91, value_dim=4, max_budget=1,
+                            precision={"fp16": capi.AZ_PREC_FP16, "bf16": capi.AZ_PREC_BF16, "fp16x3": capi.AZ_PREC_FP16X3}[a.precision])
         tower.load_weights(synth.make_blob(20, 5, Cs, 0, c_out=91, value_dim=4))
     run = (lambda b: dev.search_tower(tower, b)) if a.tower else dev.search
     run(8)                                          # warm-up
@@ -71,7 +73,7 @@ def main():
     print(json.dumps({"metric": "mcts_simulations_per_sec", "value": sims / el, "unit": "sims/s",
                       "config": {"workload": "blokus 20x20 4-player, %d concurrent games x %d sims per search, %s" % (
                                      a.games, a.budget, "NetConfig-2 tower (stem + 9 ResBlocks x 128 ch, 5 planes in, 91 policy channels, 4 values), "
-                                     "fp16 operands, random-init weights" if a.tower else "integer-hash evaluator (env + tree kernels only)"),
+                                     "%s operands, random-init weights" % a.precision if a.tower else "integer-hash evaluator (env + tree kernels only)"),
                                  "pieces_on_board": a.pieces, "leaves_per_round": a.leaves, "mean_legal_actions_at_root": float(count.mean())},
                       "ms_per_round": el / (a.searches * (-(-a.budget // a.leaves) + 3)) * 1e3, "searches": a.searches, "seconds": el, "tree": st,
                       **({"selfplay": selfplay} if selfplay else {})}))
