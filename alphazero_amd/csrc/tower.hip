@@ -407,6 +407,17 @@ typedef __attribute__((address_space(3))) void lds_void;
 // its own DMA, but a barrier alone says nothing about the pieces the OTHER waves are waiting for.
 #define AZ_DMA_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
 
+// Behind a buffer_store_dwordx4 whose offset comes in a scalar register, before anything may write the registers the
+// store takes its data from.  The MI355X reads those registers a quarter wave at a time after the store has issued,
+// and an instruction right behind it that writes one of them can get there first: v_pk_add_f32 changed what a quarter
+// of the lanes stored (the compensated mode's fp32 stream came out different from run to run), a plain v_mov_b32 /
+// v_add_f32 / v_accvgpr_read_b32 what one lane in two thousand stored; one instruction in between and the stored
+// values were the right ones every time (tools/probe/store_overwrite.hip).  The compiler pads that sequence only
+// for stores WITHOUT a scalar offset.  The data registers are the asm's operand, so whatever overwrites them is
+// ordered behind it, and the two wait states are the distance.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ void wide_store_guard(const u32x4& d) { asm volatile("s_nop 1" : : "v"(d)); }
+
 // ReLU, the 16-bit format's saturation and the padding mask in ONE v_med3_f32 per value:
 // cap is Prec::cap() for a real board cell and 0 for a padding row of the raster (whose
 // LDS copy must stay zero: neighbours read it as the convolution's zero padding).
@@ -1178,9 +1189,11 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* o
                         o.x = (unsigned)Prec<PR>::to16(v0) | ((unsigned)Prec<PR>::to16(v1) << 16);
                         o.y = (unsigned)Prec<PR>::to16(v2) | ((unsigned)Prec<PR>::to16(v3) << 16);
                     }
-                    if constexpr (R32)
-                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)},
-                                                               rrs, lane0 * 4, so * 4, 0);
+                    if constexpr (R32) {
+                        const u32x4 d4 = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+                        __builtin_amdgcn_raw_buffer_store_b128(d4, rrs, lane0 * 4, so * 4, 0);
+                        wide_store_guard(d4);
+                    }
                     if constexpr (RM == 2) {                                 // what the 16-bit copy drops, as a second 16-bit value
                         const unsigned l0 = Prec<PR>::pack2((v0 - Prec<PR>::from16((unsigned short)o.x)) * AZ_LO_SCALE,
                                                             (v1 - Prec<PR>::from16((unsigned short)(o.x >> 16))) * AZ_LO_SCALE);
@@ -1189,11 +1202,8 @@ az_conv3x3_t256s_kernel(const unsigned short* __restrict__ in, unsigned short* o
                         __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, lrs, lane0 * 2, so * 2, 0);
                     }
                     if constexpr (CAT) {                                     // hi, the remainder as it is (22 bits together), hi again
-                        // The remainders are computed in the registers the four-dword store above has just been given
-                        // (v_pk_add_f32 right behind buffer_store_dwordx4 with a scalar offset): without wait states in
-                        // between, the fp32 stream on the MI355X came out different from run to run -- a hazard the
-                        // compiler's table does not list for stores with a scalar offset.
-                        if constexpr (R32) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 3"); __builtin_amdgcn_sched_barrier(0); }
+                        // (the remainders are computed in the registers the four-dword store above has just been given:
+                        // see wide_store_guard)
                         const unsigned l0 = Prec<PR>::pack2(v0 - Prec<PR>::from16((unsigned short)o.x), v1 - Prec<PR>::from16((unsigned short)(o.x >> 16)));
                         const unsigned l1 = Prec<PR>::pack2(v2 - Prec<PR>::from16((unsigned short)o.y), v3 - Prec<PR>::from16((unsigned short)(o.y >> 16)));
                         const int soc = (16 * b + r) * (3 * C_pad) + 64 * q;

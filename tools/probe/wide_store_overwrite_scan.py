@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """Lists, per kernel of a gfx950 assembly file (hipcc --cuda-device-only -S), the VALU instructions that write a data
-register of a three- or four-dword store within a few instructions behind it, by opcode and distance.
+register of a three- or four-dword store a few instructions behind it, by opcode and by the wait states in between
+(an instruction counts one, s_nop N counts N + 1).
 
-Why: in az_conv3x3_t256s_kernel's compensated-mode epilogue, v_pk_add_f32 one instruction behind a
-buffer_store_dwordx4 with a scalar offset, writing that store's data registers, made the stored values differ from
-run to run on the MI355X; the compiler's hazard table covers such a store only without a scalar offset.  The same
-distance with v_accvgpr_read_b32, v_and_b32, v_lshlrev_b32 or v_med3_f32 as the writer occurs in the kernels whose
-outputs the tests hold bit for bit, so only packed fp32 writers are marked here.
+Why: the MI355X reads a wide store's data registers after the store has issued, a quarter wave at a time, and an
+instruction right behind the store that writes one of them can get there first (tools/probe/store_overwrite.hip:
+v_pk_add_f32 with no wait state in between changed what a quarter of the lanes stored, a plain VALU write what one
+lane in two thousand stored; behind buffer_store_dwordx4 one wait state was enough for both, behind
+global_store_dwordx4 one was not enough for the packed writer).  The compiler pads such a sequence with one wait
+state, and only when the store has no scalar offset.  Marked, and exit status 1:
+  - any writer with no wait state in between behind a buffer store with a scalar (SGPR) offset,
+  - a packed fp32 writer with fewer than two wait states in between behind any wide store.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S alphazero_amd/csrc/tower.hip -o /tmp/tower.s
-    python tools/probe/wide_store_overwrite_scan.py /tmp/tower.s [--within 4]
-Exit status 1 if a packed fp32 writer sits within two instructions of such a store."""
+    python tools/probe/wide_store_overwrite_scan.py /tmp/tower.s [--within 4]"""
 import argparse
 import collections
 import re
@@ -43,8 +46,10 @@ def main():
             if not m:
                 continue
             ops = [o.strip() for o in m.group(2).split(",")]
-            data = regs(ops[0]) if m.group(1).startswith("buffer") else regs(ops[1])
-            k, j = 0, i + 1
+            buf = m.group(1).startswith("buffer")
+            data = regs(ops[0]) if buf else regs(ops[1])
+            sgpr_off = buf and len(ops) > 3 and ops[3].split()[0].startswith("s")
+            k, j, waits = 0, i + 1, 0
             while k < a.within and j < len(lines):
                 t = lines[j].strip()
                 j += 1
@@ -53,12 +58,14 @@ def main():
                 k += 1
                 w = re.match(r"^(v_\w+)\s+(\S+?),", t)
                 if w and not w.group(1).startswith("v_cmp") and regs(w.group(2)) & data:
-                    tally[(kern, k, w.group(1))] += 1
-        for (kern, k, op), n in sorted(tally.items()):
-            mark = ""
-            if op.startswith("v_pk_") and op.endswith("f32") and k <= 2:
-                mark, bad = "   <-- packed fp32 writer right behind the store", bad + 1
-            print("%s  %s  distance %d  %s  x%d%s" % (path, kern[:64], k, op, n, mark))
+                    packed = w.group(1).startswith("v_pk_") and w.group(1).endswith("f32")
+                    flag = (sgpr_off and waits == 0) or (packed and waits < 2)
+                    tally[(kern, waits, w.group(1), "scalar offset" if sgpr_off else "no scalar offset", flag)] += 1
+                n = re.match(r"^s_nop\s+(\d+)", t)
+                waits += int(n.group(1)) + 1 if n else 1
+        for (kern, waits, op, off, flag), n in sorted(tally.items()):
+            bad += 1 if flag else 0
+            print("%s  %s  %s, %d wait state(s) in between  %s  x%d%s" % (path, kern[:64], off, waits, op, n, "   <-- too close" if flag else ""))
     return 1 if bad else 0
 
 
