@@ -412,8 +412,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 // and an instruction right behind it that writes one of them can get there first: v_pk_add_f32 changed what a quarter
 // of the lanes stored (the compensated mode's fp32 stream came out different from run to run), a plain v_mov_b32 /
 // v_add_f32 / v_accvgpr_read_b32 what one lane in two thousand stored; one instruction in between and the stored
-// values were the right ones every time (tools/probe/store_overwrite.hip).  The compiler pads that sequence only
-// for stores WITHOUT a scalar offset.  The data registers are the asm's operand, so whatever overwrites them is
+// values were the right ones every time (tools/probe/store_overwrite.hip).  The compiler pads that sequence (with
+// two wait states) only for stores WITHOUT a scalar offset.  The data registers are the asm's operand, so whatever overwrites them is
 // ordered behind it, and the two wait states are the distance.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ void wide_store_guard(const u32x4& d) { asm volatile("s_nop 1" : : "v"(d)); }

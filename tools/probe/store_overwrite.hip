@@ -8,8 +8,9 @@
 // writer by variant: 0 = v_pk_add_f32 v[10:11]; 1 = s_nop 3, then the same; 2 = v_add_f32 v10; 3 = v_mov_b32 v10;
 // 4 = v_pk_add_f32 with the store's scalar offset replaced by the immediate 0 (the case the compiler does pad:
 // here without its padding); 5 = v_pk_mul_f32 v[10:11]; 6 = s_nop 0 in between; 7 / 9 = one other VALU instruction in
-// between; 8 = v_accvgpr_read_b32 v10; 10 = v_pk_add_f32 v[12:13]; 11 / 12 = global_store_dwordx4 with and without the one
-// wait state the compiler puts there; 13 / 14 = buffer_store_dwordx2 with a packed / a plain writer right behind.
+// between; 8 = v_accvgpr_read_b32 v10; 10 = v_pk_add_f32 v[12:13]; 11 / 12 = global_store_dwordx4 with one wait state and with
+// none; 13 / 14 = buffer_store_dwordx2 with a packed / a plain writer right behind;
+// 15 = global_store_dwordx4, one wait state, plain writer; 16 = two wait states (what the compiler puts there), packed writer.
 //   hipcc --offload-arch=gfx950 -O2 tools/probe/store_overwrite.hip -o tools/probe/store_overwrite && tools/probe/store_overwrite
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) probe(float* out, float* junk, const floa
     if constexpr (V == 8) asm volatile(HEAD STORE "v_accvgpr_read_b32 v10, a0" TAIL OPS2);
     if constexpr (V == 9) asm volatile(HEAD STORE "v_mov_b32 v16, v14\n\tv_mov_b32 v10, v14" TAIL OPS2);
     if constexpr (V == 10) asm volatile(HEAD STORE "v_pk_add_f32 v[12:13], v[12:13], v[14:15]" TAIL OPS);
-    if constexpr (V == 11) {                     // global_store_dwordx4 (no scalar offset exists), the compiler's one wait state in between
+    if constexpr (V == 11) {                     // global_store_dwordx4 (no scalar offset exists), one wait state in between
         float* ptr = out + 4 * (size_t)gid;
         asm volatile(HEAD "global_store_dwordx4 %[p], v[10:13], off\n\ts_nop 0\n\tv_pk_add_f32 v[10:11], v[10:11], v[14:15]" TAIL
                      : : [a] "v"(x.x), [b] "v"(x.y), [c] "v"(x.z), [d] "v"(x.w), [k] "v"(k), [p] "v"(ptr)
@@ -70,6 +71,18 @@ __global__ void __launch_bounds__(256) probe(float* out, float* junk, const floa
     // 13 / 14: a two-dword store (writes the first two values only; the host compares those), packed and plain writer
     if constexpr (V == 13) asm volatile(HEAD "buffer_store_dwordx2 v[10:11], %[voff], %[rs], %[soff] offen\n\tv_pk_add_f32 v[10:11], v[10:11], v[14:15]" TAIL OPS);
     if constexpr (V == 14) asm volatile(HEAD "buffer_store_dwordx2 v[10:11], %[voff], %[rs], %[soff] offen\n\tv_mov_b32 v11, v14" TAIL OPS);
+    if constexpr (V == 15) {                     // one wait state, then a plain writer
+        float* ptr = out + 4 * (size_t)gid;
+        asm volatile(HEAD "global_store_dwordx4 %[p], v[10:13], off\n\ts_nop 0\n\tv_mov_b32 v10, v14" TAIL
+                     : : [a] "v"(x.x), [b] "v"(x.y), [c] "v"(x.z), [d] "v"(x.w), [k] "v"(k), [p] "v"(ptr)
+                     : "v10", "v11", "v12", "v13", "v14", "v15", "memory");
+    }
+    if constexpr (V == 16) {                     // two wait states (the compiler's padding for this store), packed writer
+        float* ptr = out + 4 * (size_t)gid;
+        asm volatile(HEAD "global_store_dwordx4 %[p], v[10:13], off\n\ts_nop 1\n\tv_pk_add_f32 v[10:11], v[10:11], v[14:15]" TAIL
+                     : : [a] "v"(x.x), [b] "v"(x.y), [c] "v"(x.z), [d] "v"(x.w), [k] "v"(k), [p] "v"(ptr)
+                     : "v10", "v11", "v12", "v13", "v14", "v15", "memory");
+    }
     if constexpr (V == 4) {
         const unsigned voff2 = voff + soff;
         asm volatile(HEAD "buffer_store_dwordx4 v[10:13], %[voff], %[rs], 0 offen\n\tv_pk_add_f32 v[10:11], v[10:11], v[14:15]" TAIL
@@ -105,22 +118,24 @@ int main() {
     float *d_in, *d_out, *d_junk;
     if (hipMalloc(&d_in, n * 4) != hipSuccess || hipMalloc(&d_out, n * 4) != hipSuccess || hipMalloc(&d_junk, n * 4) != hipSuccess) return 1;
     (void)hipMemcpy(d_in, h_in.data(), n * 4, hipMemcpyHostToDevice);
-    const char* name[15] = {"v_pk_add_f32 right behind the store", "s_nop 3, then v_pk_add_f32", "v_add_f32 right behind the store",
+    const char* name[17] = {"v_pk_add_f32 right behind the store", "s_nop 3, then v_pk_add_f32", "v_add_f32 right behind the store",
                             "v_mov_b32 right behind the store", "v_pk_add_f32 behind a store with offset 0 (no SGPR)", "v_pk_mul_f32 right behind the store",
                             "s_nop 0, then v_pk_add_f32", "one other VALU, then v_pk_add_f32", "v_accvgpr_read_b32 right behind the store",
                             "one other VALU, then v_mov_b32", "v_pk_add_f32 into the LAST two data registers", "global_store_dwordx4, s_nop 0, v_pk_add_f32",
                             "global_store_dwordx4, v_mov_b32 right behind",
-                            "buffer_store_dwordx2, v_pk_add_f32 right behind", "buffer_store_dwordx2, v_mov_b32 right behind"};
+                            "buffer_store_dwordx2, v_pk_add_f32 right behind", "buffer_store_dwordx2, v_mov_b32 right behind",
+                            "global_store_dwordx4, s_nop 0, v_mov_b32", "global_store_dwordx4, s_nop 1, v_pk_add_f32"};
     for (int pre : {0, 8, 32}) {
-        long bad[15] = {run<0>(blocks, pre, d_out, d_junk, d_in, h_in), run<1>(blocks, pre, d_out, d_junk, d_in, h_in),
+        long bad[17] = {run<0>(blocks, pre, d_out, d_junk, d_in, h_in), run<1>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<2>(blocks, pre, d_out, d_junk, d_in, h_in), run<3>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<4>(blocks, pre, d_out, d_junk, d_in, h_in), run<5>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<6>(blocks, pre, d_out, d_junk, d_in, h_in), run<7>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<8>(blocks, pre, d_out, d_junk, d_in, h_in), run<9>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<10>(blocks, pre, d_out, d_junk, d_in, h_in), run<11>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<12>(blocks, pre, d_out, d_junk, d_in, h_in),
-                        run<13>(blocks, pre, d_out, d_junk, d_in, h_in), run<14>(blocks, pre, d_out, d_junk, d_in, h_in)};
-        for (int v = 0; v < 15; ++v)
+                        run<13>(blocks, pre, d_out, d_junk, d_in, h_in), run<14>(blocks, pre, d_out, d_junk, d_in, h_in),
+                        run<15>(blocks, pre, d_out, d_junk, d_in, h_in), run<16>(blocks, pre, d_out, d_junk, d_in, h_in)};
+        for (int v = 0; v < 17; ++v)
             printf("stores in front: %2d | %-52s | lanes with other values stored: %ld of %d\n", pre, name[v], bad[v], blocks * 256);
     }
     return 0;

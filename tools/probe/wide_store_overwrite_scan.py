@@ -4,13 +4,16 @@ register of a three- or four-dword store a few instructions behind it, by opcode
 (an instruction counts one, s_nop N counts N + 1).
 
 Why: the MI355X reads a wide store's data registers after the store has issued, a quarter wave at a time, and an
-instruction right behind the store that writes one of them can get there first (tools/probe/store_overwrite.hip:
-v_pk_add_f32 with no wait state in between changed what a quarter of the lanes stored, a plain VALU write what one
-lane in two thousand stored; behind buffer_store_dwordx4 one wait state was enough for both, behind
-global_store_dwordx4 one was not enough for the packed writer).  The compiler pads such a sequence with one wait
-state, and only when the store has no scalar offset.  Marked, and exit status 1:
-  - any writer with no wait state in between behind a buffer store with a scalar (SGPR) offset,
-  - a packed fp32 writer with fewer than two wait states in between behind any wide store.
+instruction behind the store that writes one of them can get there first (tools/probe/store_overwrite.hip, 1 M lanes a
+run).  Lanes that stored other values than they held:
+  buffer_store_dwordx4 with a scalar (SGPR) offset: writer right behind: v_pk_add_f32 23 %, plain VALU up to 0.09 %;
+      one wait state in between: none.
+  global_store_dwordx4 (and buffer stores without a scalar offset): writer right behind: 23-47 %; one wait state in
+      between: v_pk_add_f32 23 %, v_mov_b32 up to 0.05 %; two wait states: none.
+  two-dword stores: none.
+The compiler pads such a sequence (s_nop 1, two wait states, on this target) only when the store has no scalar offset.  Marked, and exit
+status 1: a writer with no wait state in between; a writer with fewer than two behind a store without a scalar
+offset; a packed fp32 writer with fewer than two behind any wide store.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S alphazero_amd/csrc/tower.hip -o /tmp/tower.s
     python tools/probe/wide_store_overwrite_scan.py /tmp/tower.s [--within 4]"""
@@ -59,7 +62,7 @@ def main():
                 w = re.match(r"^(v_\w+)\s+(\S+?),", t)
                 if w and not w.group(1).startswith("v_cmp") and regs(w.group(2)) & data:
                     packed = w.group(1).startswith("v_pk_") and w.group(1).endswith("f32")
-                    flag = (sgpr_off and waits == 0) or (packed and waits < 2)
+                    flag = waits == 0 or (not sgpr_off and waits < 2) or (packed and waits < 2)
                     tally[(kern, waits, w.group(1), "scalar offset" if sgpr_off else "no scalar offset", flag)] += 1
                 n = re.match(r"^s_nop\s+(\d+)", t)
                 waits += int(n.group(1)) + 1 if n else 1
