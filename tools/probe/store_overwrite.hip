@@ -10,7 +10,8 @@
 // here without its padding); 5 = v_pk_mul_f32 v[10:11]; 6 = s_nop 0 in between; 7 / 9 = one other VALU instruction in
 // between; 8 = v_accvgpr_read_b32 v10; 10 = v_pk_add_f32 v[12:13]; 11 / 12 = global_store_dwordx4 with one wait state and with
 // none; 13 / 14 = buffer_store_dwordx2 with a packed / a plain writer right behind;
-// 15 = global_store_dwordx4, one wait state, plain writer; 16 = two wait states (what the compiler puts there), packed writer.
+// 15 = global_store_dwordx4, one wait state, plain writer; 16 = two wait states (what the compiler puts there), packed writer;
+// 17 / 18 = ds_write_b128 with a packed / a plain writer right behind.
 //   hipcc --offload-arch=gfx950 -O2 tools/probe/store_overwrite.hip -o tools/probe/store_overwrite && tools/probe/store_overwrite
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -83,6 +84,20 @@ __global__ void __launch_bounds__(256) probe(float* out, float* junk, const floa
                      : : [a] "v"(x.x), [b] "v"(x.y), [c] "v"(x.z), [d] "v"(x.w), [k] "v"(k), [p] "v"(ptr)
                      : "v10", "v11", "v12", "v13", "v14", "v15", "memory");
     }
+    if constexpr (V == 17 || V == 18) {          // the same question for LDS: ds_write_b128, packed / plain writer right behind
+        __shared__ float sh[256 * 4];
+        const unsigned laddr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)&sh[threadIdx.x * 4];
+        if constexpr (V == 17)
+            asm volatile(HEAD "ds_write_b128 %[l], v[10:13]\n\tv_pk_add_f32 v[10:11], v[10:11], v[14:15]\n\ts_waitcnt lgkmcnt(0)"
+                         : : [a] "v"(x.x), [b] "v"(x.y), [c] "v"(x.z), [d] "v"(x.w), [k] "v"(k), [l] "v"(laddr)
+                         : "v10", "v11", "v12", "v13", "v14", "v15", "memory");
+        else
+            asm volatile(HEAD "ds_write_b128 %[l], v[10:13]\n\tv_mov_b32 v10, v14\n\ts_waitcnt lgkmcnt(0)"
+                         : : [a] "v"(x.x), [b] "v"(x.y), [c] "v"(x.z), [d] "v"(x.w), [k] "v"(k), [l] "v"(laddr)
+                         : "v10", "v11", "v12", "v13", "v14", "v15", "memory");
+        __syncthreads();
+        *(float4*)(out + 4 * (size_t)gid) = *(const float4*)&sh[threadIdx.x * 4];
+    }
     if constexpr (V == 4) {
         const unsigned voff2 = voff + soff;
         asm volatile(HEAD "buffer_store_dwordx4 v[10:13], %[voff], %[rs], 0 offen\n\tv_pk_add_f32 v[10:11], v[10:11], v[14:15]" TAIL
@@ -118,15 +133,16 @@ int main() {
     float *d_in, *d_out, *d_junk;
     if (hipMalloc(&d_in, n * 4) != hipSuccess || hipMalloc(&d_out, n * 4) != hipSuccess || hipMalloc(&d_junk, n * 4) != hipSuccess) return 1;
     (void)hipMemcpy(d_in, h_in.data(), n * 4, hipMemcpyHostToDevice);
-    const char* name[17] = {"v_pk_add_f32 right behind the store", "s_nop 3, then v_pk_add_f32", "v_add_f32 right behind the store",
+    const char* name[19] = {"v_pk_add_f32 right behind the store", "s_nop 3, then v_pk_add_f32", "v_add_f32 right behind the store",
                             "v_mov_b32 right behind the store", "v_pk_add_f32 behind a store with offset 0 (no SGPR)", "v_pk_mul_f32 right behind the store",
                             "s_nop 0, then v_pk_add_f32", "one other VALU, then v_pk_add_f32", "v_accvgpr_read_b32 right behind the store",
                             "one other VALU, then v_mov_b32", "v_pk_add_f32 into the LAST two data registers", "global_store_dwordx4, s_nop 0, v_pk_add_f32",
                             "global_store_dwordx4, v_mov_b32 right behind",
                             "buffer_store_dwordx2, v_pk_add_f32 right behind", "buffer_store_dwordx2, v_mov_b32 right behind",
-                            "global_store_dwordx4, s_nop 0, v_mov_b32", "global_store_dwordx4, s_nop 1, v_pk_add_f32"};
+                            "global_store_dwordx4, s_nop 0, v_mov_b32", "global_store_dwordx4, s_nop 1, v_pk_add_f32",
+                            "ds_write_b128, v_pk_add_f32 right behind", "ds_write_b128, v_mov_b32 right behind"};
     for (int pre : {0, 8, 32}) {
-        long bad[17] = {run<0>(blocks, pre, d_out, d_junk, d_in, h_in), run<1>(blocks, pre, d_out, d_junk, d_in, h_in),
+        long bad[19] = {run<0>(blocks, pre, d_out, d_junk, d_in, h_in), run<1>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<2>(blocks, pre, d_out, d_junk, d_in, h_in), run<3>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<4>(blocks, pre, d_out, d_junk, d_in, h_in), run<5>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<6>(blocks, pre, d_out, d_junk, d_in, h_in), run<7>(blocks, pre, d_out, d_junk, d_in, h_in),
@@ -134,8 +150,9 @@ int main() {
                         run<10>(blocks, pre, d_out, d_junk, d_in, h_in), run<11>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<12>(blocks, pre, d_out, d_junk, d_in, h_in),
                         run<13>(blocks, pre, d_out, d_junk, d_in, h_in), run<14>(blocks, pre, d_out, d_junk, d_in, h_in),
-                        run<15>(blocks, pre, d_out, d_junk, d_in, h_in), run<16>(blocks, pre, d_out, d_junk, d_in, h_in)};
-        for (int v = 0; v < 17; ++v)
+                        run<15>(blocks, pre, d_out, d_junk, d_in, h_in), run<16>(blocks, pre, d_out, d_junk, d_in, h_in),
+                        run<17>(blocks, pre, d_out, d_junk, d_in, h_in), run<18>(blocks, pre, d_out, d_junk, d_in, h_in)};
+        for (int v = 0; v < 19; ++v)
             printf("stores in front: %2d | %-52s | lanes with other values stored: %ld of %d\n", pre, name[v], bad[v], blocks * 256);
     }
     return 0;
