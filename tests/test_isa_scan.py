@@ -4,7 +4,7 @@ The MI355X reads such a store's data registers after the store has issued, and a
 first: in az_conv3x3_t256s_kernel's compensated-mode epilogue v_pk_add_f32 one instruction behind
 buffer_store_dwordx4 made the stored values differ from run to run (tools/probe/store_overwrite.hip shows the effect
 in isolation).  The compiler pads the sequence (two wait states) only for stores without a scalar offset; the
-kernels keep their own wait states there (wide_store_guard in tower.hip).  This test compiles the kernel sources to
+kernels keep their own wait states there (wide_store_guard in tower.hip).  This test compiles every kernel source to
 assembly with the Makefile's flags (no GPU needed) and runs tools/probe/wide_store_overwrite_scan.py over them."""
 import concurrent.futures
 import os
@@ -16,7 +16,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-SOURCES = {"tower.hip": [], "tree.hip": ["-ffp-contract=off"], "blokus.hip": ["-ffp-contract=off"]}
+SOURCES = {"tower.hip": [], "tree.hip": ["-ffp-contract=off"], "blokus.hip": ["-ffp-contract=off"],
+           "weights.hip": ["-ffp-contract=off"], "api.hip": []}
 
 
 def _asm(src, flags, out):
@@ -29,7 +30,7 @@ def _asm(src, flags, out):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_no_write_into_a_wide_stores_data_registers_right_behind_it(tmp_path):
-    with concurrent.futures.ThreadPoolExecutor(3) as pool:
+    with concurrent.futures.ThreadPoolExecutor(5) as pool:
         asms = list(pool.map(lambda kv: _asm(kv[0], kv[1], str(tmp_path / (kv[0] + ".s"))), SOURCES.items()))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "wide_store_overwrite_scan.py"), *asms],
                        capture_output=True, text=True, timeout=120)
